@@ -1,0 +1,50 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) U-Net kernels.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/unetk.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+// UNETK_STAT_REPLICAS (unetk.h): replicas of the per-channel (sum, sumsq) accumulators; spreads the fp64
+// atomics of thousands of workgroups over many cache lines (MI355X_MICROARCH "Global float atomics":
+// every workgroup adding into one row is 14x slower).
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16> { static constexpr int E = 8; };   // elements per 16-byte piece
+template <> struct ElemTraits<float> { static constexpr int E = 4; };
+
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+
+// Direct global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int host_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define UNETK_CHECK_LAUNCH()                         \
+  do {                                               \
+    hipError_t e_ = hipGetLastError();               \
+    if (e_ != hipSuccess) return UNETK_ERR_LAUNCH;   \
+  } while (0)
