@@ -60,6 +60,114 @@ int unetk_conv3x3_fprop(const void* x, int ldx, int x_choff, const void* wpk, vo
 int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
                         int dx_choff, int n, int h, int w, int c_in, int c_out, int dtype, void* stream);
 
+/* wgrad of the same layer (autograd of unet_parts.py:16,19): dw[co,ci,kh,kw] = sum x[n,y+kh-1,x+kw-1,ci]*dy[n,y,x,co],
+ * written (accumulate=0) or added (1) into the fp32 PyTorch-layout gradient `dw` [Co][Ci][3][3].  Split-K partial
+ * sums go through `workspace` (size from unetk_wgrad_workspace_bytes, kind 0 = conv3x3, 1 = convT2x2) and are
+ * added in a fixed order: bitwise reproducible.  bf16 activations only (UNETK_ERR_DTYPE otherwise). */
+int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int c_out);
+int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                        int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int accumulate, int dtype,
+                        void* stream);
+
+/* ---- first layer: Conv2d(n_channels<=4 -> c_out, 3x3, pad 1, no bias), unet_model.py:13 -> unet_parts.py:16 ----
+ * Reads the fp32 NHWC image directly (train.py:97 hands over fp32 channels_last) and the UNPACKED parameter. */
+int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
+                              int wd, int c_in, int c_out, int dtype, void* stream);
+int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out);
+int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                              int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
+                              void* stream);
+
+/* ---- ConvTranspose2d(c_in -> c_out, k2, s2) + bias, fused with F.pad and the concat placement:
+ * unet_parts.py:53 (aten::conv_transpose2d), :59-63 (constant_pad_nd), :67 (cat).
+ * x [n,h,w,c_in]; y = channel slice [y_choff, y_choff+c_out) of the [n,hs,ws,ldy] concat buffer;
+ * y[n, pad_t+2i+a, pad_l+2j+b, co] = bias[co] + sum_ci x[n,i,j,ci]*w[ci,co,a,b].  The pad border itself is
+ * zeroed by unetk_zero_pad_border.  wpk = unetk_pack_weight(kind 2 / 3). */
+int unetk_convT2x2_fwd(const void* x, int ldx, const void* wpk, const float* bias, void* y, int ldy, int y_choff,
+                       int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype,
+                       void* stream);
+int unetk_convT2x2_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int n, int h,
+                         int w, int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream);
+/* dw [c_in][c_out][2][2] fp32; the bias gradient is a plain per-channel sum (unetk_bn_relu_bwd_* is not involved):
+ * it is produced by unetk_channel_sum. */
+int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int dy_choff, float* dw, void* workspace,
+                         int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t,
+                         int pad_l, int accumulate, int dtype, void* stream);
+int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int pad_t, int pad_l, int h_up, int w_up,
+                          int dtype, void* stream);
+/* out[c] = sum over images and the window [win_y,win_y+win_h) x [win_x,win_x+win_w) of x[n,y,x,c];
+ * scratch: c doubles. */
+int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int win_y, int win_x, int win_h, int win_w,
+                      double* scratch, float* out, int dtype, void* stream);
+
+/* ---- BatchNorm2d + ReLU: unet_parts.py:17-18,20-21 (aten::batch_norm, aten::relu_) ---------------------------
+ * train: statistics come from the conv epilogue (`stats`, [UNETK_STAT_REPLICAS][c][2] doubles); finalize turns
+ * them into scale/shift (+ mean/invstd for backward), updates running_mean/var with momentum and the UNBIASED
+ * variance, and increments num_batches_tracked.  eval: scale/shift from the running statistics. */
+int unetk_bn_train_finalize(const double* stats, int64_t count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float eps, float* scale, float* shift, float* mean, float* invstd, int c, void* stream);
+int unetk_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, float* scale, float* shift, int c, void* stream);
+/* out = relu(y*scale + shift) */
+int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                        int64_t npix, int c, int dtype, void* stream);
+/* backward through ReLU and train-mode BN: reduce (sums [REPLICAS][c][2] doubles, zeroed by the caller) ->
+ * finalize (dgamma, dbeta, coef [3][c]) -> apply (dy = coef0*dz - coef1 - coef2*(y-mean)). */
+int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, double* sums, int64_t npix, int c, int dtype,
+                             void* stream);
+int unetk_bn_relu_bwd_finalize(const double* sums, int64_t count, const float* gamma, const float* invstd, float* dgamma,
+                               float* dbeta, float* coef, int c, void* stream);
+int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,
+                            const float* mean, const float* coef, void* dy, int lddy, int64_t npix, int c, int dtype,
+                            void* stream);
+
+/* ---- MaxPool2d(2): unet_parts.py:34 (aten::max_pool2d), floor mode ---------------------------------------------
+ * bwd: dx = (dskip ? dskip : 0) + dpool routed to the first maximum of each window; `dskip` is the gradient the
+ * same tensor receives through the skip connection (unet_model.py:31-34), folded in here. dx may alias dskip. */
+int unetk_maxpool2x2_fwd(const void* x, int ldx, void* out, int ldo, int n, int h, int w, int c, int dtype,
+                         void* stream);
+int unetk_maxpool2x2_bwd(const void* x, int ldx, const void* dpool, int lddp, const void* dskip, int ldds, void* dx,
+                         int lddx, int n, int h, int w, int c, int dtype, void* stream);
+
+/* ---- Upsample(scale 2, bilinear, align_corners=True) fused with F.pad + concat placement: unet_parts.py:50,59-67
+ * `out`/`dcat` point at the first channel of the up-sampled slice of the [n,hs,ws,ld] concat buffer. */
+int unetk_bilinear2x_fwd(const void* x, int ldx, void* out, int ldo, int n, int h, int w, int c, int hs, int ws,
+                         int pad_t, int pad_l, int dtype, void* stream);
+int unetk_bilinear2x_bwd(const void* dcat, int ldd, void* dx, int lddx, int n, int h, int w, int c, int hs, int ws,
+                         int pad_t, int pad_l, int dtype, void* stream);
+/* copy a [npix, c] channel slice between buffers of different pitch (torch.cat's skip half, unet_parts.py:67,
+ * when the caller did not produce the skip tensor inside the concat buffer already) */
+int unetk_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, int64_t npix, int c, int dtype,
+                        void* stream);
+
+/* ---- OutConv: Conv2d(c_in -> n_classes, k1) + bias: unet_parts.py:74 --------------------------------------------
+ * w [n_classes][c_in] fp32 (the parameter itself), logits NHWC [npix][ldo >= n_classes]. */
+int unetk_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int64_t npix,
+                      int c_in, int n_classes, int dtype, void* stream);
+int unetk_conv1x1_dgrad(const void* dl, int lddl, const float* w, void* dx, int lddx, int64_t npix, int c_in,
+                        int n_classes, int dtype, void* stream);
+int64_t unetk_conv1x1_wgrad_workspace_bytes(int c_in, int n_classes);
+int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float* dw, float* db, void* workspace,
+                        int64_t workspace_bytes, int64_t npix, int c_in, int n_classes, int dtype, void* stream);
+
+/* ---- loss: train.py:81,102-111 (CrossEntropyLoss | BCEWithLogitsLoss) + utils/dice_score.py:25-28 (dice_loss) --
+ * fwd: sums4 (4 doubles, scratch) and out4 = {loss, dice, alpha, beta} (floats; alpha/beta feed bwd).
+ * bwd: dlogits = grad_out * dloss/dlogits (grad_out: device float, NULL = 1). mask is int64 [npix]. */
+int unetk_seg_loss_fwd(const void* logits, int ldz, const int64_t* mask, int64_t npix, int n_classes, float eps,
+                       double* sums4, float* out4, int dtype, void* stream);
+int unetk_seg_loss_bwd(const void* logits, int ldz, const int64_t* mask, int64_t npix, int n_classes,
+                       const float* out4, const float* grad_out, void* dlogits, int lddz, int dtype, void* stream);
+/* dice_coeff (utils/dice_score.py:5-17) over n_groups groups of group_size contiguous fp32 elements:
+ * dice_out = mean_g (2*sum(x*t)+eps)/(S_g+eps), S_g = sum x + sum t, replaced by 2*sum(x*t) where it is 0.
+ * sums: n_groups*3 doubles scratch; coef: n_groups*2 floats for bwd (may be NULL).
+ * bwd: dinput = sign * grad_out * d dice/d input. */
+int unetk_dice_fwd(const float* input, const float* target, int n_groups, int64_t group_size, float eps, double* sums,
+                   float* dice_out, float* coef, void* stream);
+int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out, float sign, int n_groups,
+                   int64_t group_size, float* dinput, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

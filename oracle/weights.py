@@ -1,38 +1,53 @@
 """TEST INFRASTRUCTURE ONLY -- closed-form, RNG-free tensors for parity tests.
 
 A full fp32 UNet checkpoint is 124 MB, too big to commit, so goldens are generated from
-weights every machine can rebuild bit-identically: each tensor is `scale*sin(a*i+b)+offset`
-over its flat index i, with (a, b) derived from a CRC of the tensor's state_dict key
-("Whole-net weights").  The same generator fills inputs and masks.
+weights every machine can rebuild bit-identically: each tensor is `scale*u+offset` with
+u ~ U[-1,1) hashed (SplitMix64, integer arithmetic only) from a CRC of the tensor's state_dict
+key and the flat element index ("Whole-net weights").  The same
+generator fills inputs and masks.
 """
 import zlib
 
 import numpy as np
 
 
-def _ab(name: str):
-    h = zlib.crc32(name.encode())
-    a = 0.37 + (h & 0xFFFF) / 65536.0          # in [0.37, 1.37)
-    b = ((h >> 16) & 0xFFFF) / 65536.0 * 6.0   # in [0, 6)
-    return a, b
+def _seed(name: str) -> np.uint64:
+    return np.uint64(zlib.crc32(name.encode())) * np.uint64(0x9E3779B97F4A7C15)
+
+
+def _splitmix64(x):
+    """SplitMix64 finaliser on uint64 arrays: pure integer arithmetic, identical on every machine."""
+    with np.errstate(over='ignore'):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _uniform(name: str, n: int):
+    """n reproducible uniforms in [-1, 1): hash(key, index) -> 53-bit mantissa.  (A plain sinusoid over the
+    flat index makes conv outputs nearly cancel, which leaves BatchNorm channels with variance at rounding
+    level and lets even the reference's fp32 and fp64 runs disagree; hashed values are well conditioned.)"""
+    with np.errstate(over='ignore'):
+        idx = np.arange(n, dtype=np.uint64) + _seed(name)
+    bits = _splitmix64(idx) >> np.uint64(11)
+    return bits.astype(np.float64) * (2.0 / (1 << 53)) - 1.0
 
 
 def wave(name: str, shape, scale=1.0, offset=0.0, dtype=np.float32):
-    """scale*sin(a*i+b)+offset over the flat (C-order) index, fp64 math, cast once."""
+    """scale*u + offset with u ~ U[-1,1) hashed from (name, flat index); fp64 math, cast once."""
     n = int(np.prod(shape)) if len(shape) else 1
-    a, b = _ab(name)
-    i = np.arange(n, dtype=np.float64)
-    v = scale * np.sin(a * i + b) + offset
-    return v.astype(dtype).reshape(shape)
+    return (scale * _uniform(name, n) + offset).astype(dtype).reshape(shape)
 
 
 def int_wave(name: str, shape, n_values: int):
-    """Deterministic integer field in [0, n_values) (segmentation masks)."""
-    n = int(np.prod(shape))
-    a, b = _ab(name)
-    i = np.arange(n, dtype=np.float64)
-    v = np.floor((np.sin(a * 0.05 * i + b) * 0.5 + 0.5) * n_values * 0.999999)
-    return v.astype(np.int64).reshape(shape)
+    """Deterministic integer field in [0, n_values) made of 4x4 blocks (segmentation-mask like)."""
+    shape = tuple(shape)
+    coarse = tuple(shape[:-2]) + ((shape[-2] + 3) // 4, (shape[-1] + 3) // 4)
+    u = (_uniform(name, int(np.prod(coarse))) * 0.5 + 0.5).reshape(coarse)
+    v = np.floor(u * n_values * 0.999999).astype(np.int64)
+    v = np.repeat(np.repeat(v, 4, axis=-2), 4, axis=-1)
+    return np.ascontiguousarray(v[..., :shape[-2], :shape[-1]])
 
 
 def tensor_for_key(key: str, shape, dtype_name: str):

@@ -1,0 +1,477 @@
+// The network's first convolution: Conv2d(n_channels -> 64, 3x3, pad 1, no bias) with n_channels <= 4
+// (unet_model.py:13 -> unet_parts.py:16; images have 3 channels, train.py:196).
+//
+// K = 9*Cin = 27 is MFMA-hostile as an implicit GEMM over channel chunks, and the layer is HBM-bound anyway
+// (it writes 64 channels per pixel and reads 3), so it gets its own kernel: the fp32 image tile (with halo) is
+// converted once into LDS as [pixel][4 channels], the GEMM-K index is k = tap*4 + ci (36, zero padded), and each
+// lane assembles its A fragment from two 8-byte (bf16) or one 16-byte (fp32) LDS reads.  Epilogue (rounding,
+// fused BatchNorm statistics, NB-wide channel stores) is the same as conv_igemm.hip.
+//
+// The matching weight gradient uses the transposed problem: rows = k (tap, ci), cols = co, GEMM-K = pixels.
+#include "conv_common.h"
+
+namespace {
+
+struct FirstParams {
+  const float* x;     // fp32 NHWC image, pitch ldx
+  const float* w;     // parameter [Cout][Cin][3][3]
+  void* y;
+  double* stats;
+  int N, H, W, Cin, Cout, ldx, ldy;
+  int tiles_x, tiles_y, n_tiles;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int NB = 2, BN = 64;
+  constexpr int STEPS = (36 + 2 * E - 1) / (2 * E);     // bf16: 3 (k < 48), fp32: 5 (k < 40)
+  constexpr int PXB = 4 * sizeof(T);                     // LDS bytes per pixel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_x = smem;                                    // [340][4] T
+  char* lds_w = smem + 340 * 16;                         // [STEPS][NB][64 lanes][16 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nt = bid % P.n_tiles; bid /= P.n_tiles;
+  const int tx = bid % P.tiles_x; bid /= P.tiles_x;
+  const int ty = bid % P.tiles_y;
+  const int img = bid / P.tiles_y;
+  const int y0 = ty * 8, x0 = tx * 32;
+
+  // ---- image tile + halo -> LDS, converted to T
+  const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
+  for (int p = tid; p < 340; p += 256) {
+    const int hr = p / 34, hc = p - hr * 34;
+    const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+      const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
+      for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
+    }
+    T* dst = reinterpret_cast<T*>(lds_x + p * PXB);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = from_f32<T>(v[c]);
+  }
+  // ---- weights -> B fragments (lane (j,h), step s, element e: k = s*2E + h*E + e, channel nt*64 + NB*j + nb)
+  for (int i = tid; i < STEPS * NB * 64 * E; i += 256) {
+    const int e = i % E;
+    int r = i / E;
+    const int l = r % 64; r /= 64;
+    const int nb = r % NB;
+    const int s = r / NB;
+    const int k = s * 2 * E + (l >> 5) * E + e;
+    const int tap = k >> 2, ci = k & 3;
+    const int co = nt * BN + NB * (l & 31) + nb;
+    float v = 0.f;
+    if (tap < 9 && ci < P.Cin) v = P.w[((size_t)co * P.Cin + ci) * 9 + tap];
+    reinterpret_cast<T*>(lds_w)[i] = from_f32<T>(v);
+  }
+  __syncthreads();
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    uint4 a[2], b[NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = 2 * wid + mb;
+      if constexpr (sizeof(T) == 2) {
+        const int tapA = 4 * s + 2 * h, tapB = tapA + 1;
+        uint2 lo = {0u, 0u}, hi = {0u, 0u};
+        if (tapA < 9) lo = *reinterpret_cast<const uint2*>(lds_x + ((row + tapA / 3) * 34 + j + tapA % 3) * PXB);
+        if (tapB < 9) hi = *reinterpret_cast<const uint2*>(lds_x + ((row + tapB / 3) * 34 + j + tapB % 3) * PXB);
+        a[mb] = uint4{lo.x, lo.y, hi.x, hi.y};
+      } else {
+        const int tap = 2 * s + h;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (tap < 9) v = *reinterpret_cast<const uint4*>(lds_x + ((row + tap / 3) * 34 + j + tap % 3) * PXB);
+        a[mb] = v;
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const uint4*>(lds_w + ((s * NB + nb) * 64 + lane) * 16);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], a[mb], b[nb]);
+  }
+
+  // ---- epilogue (same contract as conv_igemm.hip)
+  const int ch0 = nt * BN + NB * j;
+  float ssum[NB], ssq[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
+  T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int yy = y0 + 2 * wid + mb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (yy < P.H && xx < P.W) {
+        float v[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
+          v[nb] = f;
+          ssum[nb] += f;
+          ssq[nb] += f * f;
+        }
+        store_channels<T, NB>(yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0, v);
+      }
+    }
+  }
+  if (P.stats != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
+      ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (h == 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
+        red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const float v = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+      double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+      unsafeAtomicAdd(dst, (double)v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, bf16
+__device__ uint4 g_zero_page_first[8];
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct FirstWgradParams {
+  const float* x;
+  const void* dy;
+  float* slab;        // [nsplit][col_tiles][64 rows (k)][64 cols]
+  int N, H, W, Cin, Cout, ldx, lddy;
+  int tiles_x, tiles_y, ntiles, nsplit, col_tiles;
+};
+
+// rows i = k = tap*4 + ci (36 used of 64), cols = 64 output channels, GEMM-K = pixels.
+// Each wave takes 2 of the 8 tile rows and keeps a full 64x64 accumulator; waves are summed through LDS at the end.
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_dy = smem;                 // [256 px][64 co] bf16, 128-B rows, 16-B pieces XOR-swizzled
+  char* lds_x = smem + 256 * 128;      // [340][4] bf16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.x % P.col_tiles, split = blockIdx.x / P.col_tiles;
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int r = lane & 31, h = lane >> 5;
+
+  // B (dy) transposed-read addresses: [col block jb][ks][rd]
+  int addrB[2][2][2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int p = ks * 16 + 8 * (g >> 1) + 4 * rd + q;
+        const int c = jb * 4 + 2 * (g & 1) + (pp >> 1);
+        addrB[jb][ks][rd] = p * 128 + ((c ^ (((p >> 1) & 1) << 2)) << 4) + (pp & 1) * 8;
+      }
+  // A (image) gather: row i = ib*32 + r  ->  tap = i>>2, ci = i&3 ; element jj is pixel 8h + jj of the k-step
+  int addrA[2];
+  bool rowok[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const int i = ib * 32 + r, tap = i >> 2, ci = i & 3;
+    rowok[ib] = tap < 9;
+    const int tp = tap < 9 ? tap : 0;
+    addrA[ib] = ((tp / 3) * 34 + (tp % 3) + 8 * h) * 8 + ci * 2;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ib][jb][i] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_first);
+  const int lp = lane >> 3, ls = lane & 7;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx = tt % P.tiles_x; tt /= P.tiles_x;
+    const int ty = tt % P.tiles_y;
+    const int img = tt / P.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // dy tile by LDS-DMA
+    const bf16* dimg = reinterpret_cast<const bf16*>(P.dy) + (size_t)img * P.H * P.W * P.lddy + ct * 64;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int fi = f * 4 + wid;
+      const int p = fi * 8 + lp;
+      const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+      const int c = ls ^ (((p >> 1) & 1) << 2);
+      const char* src = zero;
+      if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(dimg + (size_t)(yy * P.W + xx) * P.lddy + c * 8);
+      glds16(src, lds_dy + fi * 1024);
+    }
+    // image halo tile, fp32 -> bf16
+    const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
+    for (int p = tid; p < 340; p += 256) {
+      const int hr = p / 34, hc = p - hr * 34;
+      const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+        const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
+        for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
+      }
+      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *reinterpret_cast<bf16x4*>(lds_x + p * 8) = o;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wid + rr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 bfr[2], afr[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          const char* base = lds_dy + row * 4096;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(base + addrB[jb][ks][0]));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(base + addrB[jb][ks][1]));
+          bfr[jb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          const char* base = lds_x + (row * 34 + ks * 16) * 8 + addrA[ib];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const bf16 v = *reinterpret_cast<const bf16*>(base + jj * 8);
+            afr[ib][jj] = rowok[ib] ? v : (bf16)0.f;
+          }
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+            acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- sum the 4 waves through LDS, write the block's partial [64][64]
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* red = reinterpret_cast<float*>(smem);   // [64][64] floats = 16 KB
+  for (int i = tid; i < 64 * 64; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        atomicAdd(&red[row * 64 + jb * 32 + r], acc[ib][jb][i]);
+      }
+  __syncthreads();
+  float* out = P.slab + ((size_t)split * P.col_tiles + ct) * 4096;
+  for (int i = tid; i < 4096; i += 256) out[i] = red[i];
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, fp32
+// Same problem on the exact-fp32 MFMA (32x32x2): rows i = k = tap*4+ci (two 32-row blocks, 36 used), cols = a
+// 32-channel slice of co, GEMM-K = pixels two at a time; no transposes (one float per lane per operand).
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_f32_kernel(FirstWgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_dy = smem;                 // [256 px][32 co] fp32, 128-B rows
+  char* lds_x = smem + 256 * 128;      // [340][4] fp32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = blockIdx.x % P.col_tiles, split = blockIdx.x / P.col_tiles;    // col tiles of 32 here
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+  const int r = lane & 31, h = lane >> 5;
+  int addrA[2];
+  bool rowok[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const int i = ib * 32 + r, tap = i >> 2, ci = i & 3;
+    rowok[ib] = tap < 9;
+    const int tp = tap < 9 ? tap : 0;
+    addrA[ib] = ((tp / 3) * 34 + (tp % 3) + h) * 16 + ci * 4;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ib][i] = 0.f;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_first);
+  const int lp = lane >> 3, ls = lane & 7;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx = tt % P.tiles_x; tt /= P.tiles_x;
+    const int ty = tt % P.tiles_y;
+    const int img = tt / P.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float* dimg = reinterpret_cast<const float*>(P.dy) + (size_t)img * P.H * P.W * P.lddy + ct * 32;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int fi = f * 4 + wid;
+      const int p = fi * 8 + lp;
+      const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+      const char* src = zero;
+      if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(dimg + (size_t)(yy * P.W + xx) * P.lddy + ls * 4);
+      glds16(src, lds_dy + fi * 1024);
+    }
+    const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
+    for (int p = tid; p < 340; p += 256) {
+      const int hr = p / 34, hc = p - hr * 34;
+      const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+        const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
+        for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
+      }
+      *reinterpret_cast<f32x4*>(lds_x + p * 16) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wid + rr;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const float bv = *reinterpret_cast<const float*>(lds_dy + (row * 32 + 2 * s + h) * 128 + r * 4);
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          float av = *reinterpret_cast<const float*>(lds_x + (row * 34 + 2 * s) * 16 + addrA[ib]);
+          av = rowok[ib] ? av : 0.f;
+          acc[ib] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ib], 0, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* red = reinterpret_cast<float*>(smem);   // [64][32]
+  for (int i = tid; i < 64 * 32; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) atomicAdd(&red[(ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r], acc[ib][i]);
+  __syncthreads();
+  // slab layout shared with the bf16 kernel: [split][64-col tile][64 rows][64 cols]
+  float* out = P.slab + ((size_t)split * (P.col_tiles / 2) + (ct >> 1)) * 4096 + (ct & 1) * 32;
+  for (int i = tid; i < 64 * 32; i += 256) out[(i >> 5) * 64 + (i & 31)] = red[i];
+}
+
+// dw[co][ci][tap] = sum_split slab[split][ct][k = tap*4+ci][co - ct*64]
+__global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ slab, float* dw, int nsplit, int col_tiles,
+                                               int Cin, int Cout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Cin * 9) return;
+  const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+  const int ct = co >> 6, c = co & 63, k = tap * 4 + ci;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += slab[((size_t)sp * col_tiles + ct) * 4096 + k * 64 + c];
+  dw[idx] = s;
+}
+
+int first_nsplit(int ntiles, int col_tiles) {
+  int ns = 512 / col_tiles;
+  if (ns < 1) ns = 1;
+  if (ns > ntiles) ns = ntiles;
+  return ns;
+}
+
+}  // namespace
+
+extern "C" {
+
+int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
+                              int wd, int c_in, int c_out, int dtype, void* stream) {
+  if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || ldx < c_in || ldy < c_out) return UNETK_ERR_SHAPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) || (ldy * es) % 16) return UNETK_ERR_ALIGN;
+  if ((long)h * wd * ldy >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+  FirstParams P{};
+  P.x = x; P.w = w; P.y = y; P.stats = stats;
+  P.N = n; P.H = h; P.W = wd; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.ldy = ldy;
+  P.tiles_x = host_cdiv(wd, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = c_out / 64;
+  const long nblk = (long)n * P.tiles_x * P.tiles_y * P.n_tiles;
+  if (nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  const size_t lds = 340 * 16 + 5 * 2 * 1024;
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(conv_first_fprop_kernel<bf16>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
+  else
+    hipLaunchKernelGGL(conv_first_fprop_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out) {
+  if (n <= 0 || h <= 0 || w <= 0 || c_out <= 0 || c_out % 64) return UNETK_ERR_SHAPE;
+  const int ntiles = n * host_cdiv(h, 8) * host_cdiv(w, 32);
+  return (int64_t)first_nsplit(ntiles, c_out / 64) * (c_out / 64) * 4096 * sizeof(float);
+}
+
+int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                              int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
+                              void* stream) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int64_t need = unetk_conv3x3_first_wgrad_workspace_bytes(n, h, w, c_out);
+  if (need < 0) return (int)need;
+  if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
+  if (c_in < 1 || c_in > 4 || ldx < c_in || lddy < c_out) return UNETK_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (lddy * (dtype == UNETK_BF16 ? 2 : 4)) % 16) return UNETK_ERR_ALIGN;
+  FirstWgradParams P{};
+  P.x = x; P.dy = dy; P.slab = (float*)workspace;
+  P.N = n; P.H = h; P.W = w; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.lddy = lddy;
+  P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
+  P.col_tiles = c_out / 64;
+  P.nsplit = first_nsplit(P.ntiles, P.col_tiles);
+  if (dtype == UNETK_BF16) {
+    const size_t lds = 256 * 128 + 340 * 8;
+    hipLaunchKernelGGL(conv_first_wgrad_bf16_kernel, dim3(P.nsplit * P.col_tiles), dim3(256), lds, (hipStream_t)stream,
+                       P);
+  } else {
+    FirstWgradParams Q = P;
+    Q.col_tiles = c_out / 32;     // the fp32 kernel works on 32-channel column tiles, same slab layout
+    const size_t lds = 256 * 128 + 340 * 16;
+    hipLaunchKernelGGL(conv_first_wgrad_f32_kernel, dim3(Q.nsplit * Q.col_tiles), dim3(256), lds, (hipStream_t)stream,
+                       Q);
+  }
+  UNETK_CHECK_LAUNCH();
+  const int total = c_out * c_in * 9;
+  hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dw, P.nsplit, P.col_tiles, c_in, c_out);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

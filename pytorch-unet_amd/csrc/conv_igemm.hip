@@ -17,7 +17,7 @@
 //         1 PWT    ConvTranspose2d k2 s2 forward: pointwise GEMM with N = 4*Co, pixel-shuffle store into
 //                  the concat buffer at a channel offset, + bias               unet_parts.py:53,62-67
 //         2 CTD    ConvTranspose2d k2 s2 dgrad: 4 stride-2 taps as outer K iterations
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -36,44 +36,10 @@ struct ConvParams {
   int tiles_x, tiles_y, n_tiles;
 };
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-  static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
-    f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], c, 0, 0, 0);
-  }
-};
-
 template <int MODE> struct Geo;
 template <> struct Geo<0> { static constexpr int TAPS = 9, KS = 2, NPIX = 10 * 34, OUTER = 1; };
 template <> struct Geo<1> { static constexpr int TAPS = 1, KS = 4, NPIX = 256, OUTER = 1; };
 template <> struct Geo<2> { static constexpr int TAPS = 1, KS = 4, NPIX = 256, OUTER = 4; };
-
-template <typename T, int NB> __device__ __forceinline__ void store_channels(T* p, const float (&v)[NB]) {
-  if constexpr (sizeof(T) == 2) {
-    if constexpr (NB == 2) {
-      bf16x2 o = {(bf16)v[0], (bf16)v[1]};
-      *reinterpret_cast<bf16x2*>(p) = o;
-    } else {
-      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *reinterpret_cast<bf16x4*>(p) = o;
-    }
-  } else {
-    if constexpr (NB == 2) {
-      f32x2 o = {v[0], v[1]};
-      *reinterpret_cast<f32x2*>(p) = o;
-    } else {
-      f32x4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(p) = o;
-    }
-  }
-}
 
 template <typename T, int NB, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
@@ -181,9 +147,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
     const int io = iter_offset(it);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (poff[r] >= 0) v = *reinterpret_cast<const uint4*>(ximg + poff[r] + io);
-      stage[r] = v;
+      // ALWAYS issue the load (clamped address, result discarded for padding): the counted s_waitcnt below
+      // relies on every wave having exactly R prefetch loads younger than its LDS-DMA.
+      // (the zero fill for padding is applied when the piece is written to LDS, so that nothing here consumes
+      // a load result and forces an early s_waitcnt)
+      stage[r] = *reinterpret_cast<const uint4*>(ximg + (poff[r] >= 0 ? poff[r] : 0) + io);
     }
   };
 
@@ -194,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (r * 256 + tid < NPIECE) *reinterpret_cast<uint4*>(lds_in + ldst[r]) = stage[r];
+      if (r * 256 + tid < NPIECE)
+        *reinterpret_cast<uint4*>(lds_in + ldst[r]) = poff[r] >= 0 ? stage[r] : uint4{0u, 0u, 0u, 0u};
     // weights of this chunk: WFRAGS x 1 KiB, fragment order, straight into LDS
     {
       const char* wsrc = wbase + (size_t)it * (WFRAGS * 1024) + lane * 16;

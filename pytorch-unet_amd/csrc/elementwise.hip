@@ -1,0 +1,638 @@
+// HBM-bound kernels of the U-Net hot path: BatchNorm(+ReLU) forward/backward, MaxPool2d(2) forward/backward,
+// bilinear x2 (align_corners=True) up-sampling fused with pad + concat placement, channel-slice copies.
+// All of them move 16 bytes per lane per access (cdna_hip_programming.md Guideline 13) over NHWC tensors whose
+// pixel pitch `ld` may exceed the channel count (channel slices of the decoder's concat buffer).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec {
+  static constexpr int E = ElemTraits<T>::E;
+  static __device__ __forceinline__ void load(const T* p, float (&v)[E]) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+    } else {
+      const f32x4 f = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = f[i];
+    }
+  }
+  static __device__ __forceinline__ void store(T* p, const float (&v)[E]) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
+      *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, b);
+    } else {
+      f32x4 f = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f);
+    }
+  }
+};
+
+constexpr int kMaxGrid = 256 * 8;   // memory-bound grids: ~8 blocks per CU, grid-stride the rest (Guideline 11)
+
+inline int ew_grid(long work_items, int per_block = 256) {
+  long g = (work_items + per_block - 1) / per_block;
+  return (int)(g > kMaxGrid ? kMaxGrid : (g < 1 ? 1 : g));
+}
+
+// ------------------------------------------------------------------------------------------ BN finalize
+// unet_parts.py:17,20 (aten::batch_norm, training): biased variance for normalisation, unbiased for the
+// running estimate, momentum update, num_batches_tracked += 1.
+__global__ void bn_train_finalize_kernel(const double* __restrict__ stats, long count, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* running_mean, float* running_var,
+                                         long long* nbt, float momentum, float eps, float* scale, float* shift,
+                                         float* mean_out, float* invstd_out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int r = 0; r < UNETK_STAT_REPLICAS; ++r) {
+    s += stats[((size_t)r * C + c) * 2 + 0];
+    q += stats[((size_t)r * C + c) * 2 + 1];
+  }
+  const double mean = s / (double)count;
+  double var = q / (double)count - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = b - (float)mean * g * invstd;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * invstd;
+  shift[c] = b - rm[c] * g * invstd;
+}
+
+// ------------------------------------------------------------------------------------------ BN + ReLU apply
+// out = relu(y*scale + shift)   (unet_parts.py:17-18, 20-21 fused)
+template <typename T>
+__global__ void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, T* __restrict__ out, int ldo, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const long total = npix * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx / ppp;
+    const int c0 = (int)(idx - pix * ppp) * E;
+    float v[E], sc[E], sh[E];
+    Vec<T>::load(y + pix * ldy + c0, v);
+#pragma unroll
+    for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; }
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+    Vec<T>::store(out + pix * ldo + c0, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ BN + ReLU backward
+// pass 1: per-channel  S1 = sum dz,  S2 = sum dz*xhat   with dz = dout * [bn(y) > 0], xhat = (y-mean)*invstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ dout, int lddo,
+                                                                 const T* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, double* sums,
+                                                                 long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[256 * E * 2];   // [pieces in group][E][2] <= 256*E*2 floats
+  const int ppp = C / E;
+  const int pg = ppp < 256 ? ppp : 256;           // pieces handled by this block's channel group
+  const int lanes = 256 / pg;                     // pixel lanes
+  const int piece_in_group = threadIdx.x % pg;
+  const int plane = threadIdx.x / pg;
+  const int piece = blockIdx.y * 256 + piece_in_group;
+  const bool active = plane < lanes && piece < ppp;
+  const int c0 = piece * E;
+  for (int i = threadIdx.x; i < pg * E * 2; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float s1[E], s2[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) s1[i] = s2[i] = 0.f;
+  if (active) {
+    float sc[E], sh[E], mu[E], is[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+    }
+    for (long pix = (long)blockIdx.x * lanes + plane; pix < npix; pix += (long)gridDim.x * lanes) {
+      float g[E], v[E];
+      Vec<T>::load(dout + pix * lddo + c0, g);
+      Vec<T>::load(y + pix * ldy + c0, v);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float dz = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+        s1[i] += dz;
+        s2[i] += dz * (v[i] - mu[i]) * is[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      atomicAdd(&red[(piece_in_group * E + i) * 2 + 0], s1[i]);
+      atomicAdd(&red[(piece_in_group * E + i) * 2 + 1], s2[i]);
+    }
+  }
+  __syncthreads();
+  double* dst = sums + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C + blockIdx.y * 256 * E) * 2;
+  const int nvals = pg * E * 2;
+  for (int i = threadIdx.x; i < nvals; i += 256)
+    if (blockIdx.y * 256 * E + i / 2 < C) unsafeAtomicAdd(dst + i, (double)red[i]);
+}
+
+// finalize: dgamma = S2, dbeta = S1; coefficients of  dy = a*dz - b - c*(y - mean)
+__global__ void bn_relu_bwd_finalize_kernel(const double* __restrict__ sums, long count, const float* __restrict__ gamma,
+                                            const float* __restrict__ invstd, float* dgamma, float* dbeta, float* coef,
+                                            int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int r = 0; r < UNETK_STAT_REPLICAS; ++r) {
+    s1 += sums[((size_t)r * C + c) * 2 + 0];
+    s2 += sums[((size_t)r * C + c) * 2 + 1];
+  }
+  const float g = gamma ? gamma[c] : 1.f, is = invstd[c];
+  if (dgamma) dgamma[c] = (float)s2;
+  if (dbeta) dbeta[c] = (float)s1;
+  const double a = (double)g * is;
+  coef[c] = (float)a;
+  coef[C + c] = (float)(a * s1 / (double)count);
+  coef[2 * C + c] = (float)(a * s2 / (double)count * is);
+}
+
+template <typename T>
+__global__ void bn_relu_bwd_apply_kernel(const T* __restrict__ dout, int lddo, const T* __restrict__ y, int ldy,
+                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                         const float* __restrict__ mean, const float* __restrict__ coef,
+                                         T* __restrict__ dy, int lddy, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const long total = npix * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx / ppp;
+    const int c0 = (int)(idx - pix * ppp) * E;
+    float g[E], v[E], o[E];
+    Vec<T>::load(dout + pix * lddo + c0, g);
+    Vec<T>::load(y + pix * ldy + c0, v);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int c = c0 + i;
+      const float dz = fmaf(v[i], scale[c], shift[c]) > 0.f ? g[i] : 0.f;
+      o[i] = coef[c] * dz - coef[C + c] - coef[2 * C + c] * (v[i] - mean[c]);
+    }
+    Vec<T>::store(dy + pix * lddy + c0, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ MaxPool2d(2)
+// unet_parts.py:34: k2 s2, floor mode -- an odd last row/column is dropped.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int H, int W,
+                                   int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E, Ho = H / 2, Wo = W / 2;
+  const long total = (long)N * Ho * Wo * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int c0 = (int)(r % ppp) * E; r /= ppp;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long n = r / Ho;
+    const T* src = x + ((n * H + 2 * oy) * W + 2 * ox) * ldx + c0;
+    float a[E], b[E], c[E], d[E];
+    Vec<T>::load(src, a);
+    Vec<T>::load(src + ldx, b);
+    Vec<T>::load(src + (long)W * ldx, c);
+    Vec<T>::load(src + (long)W * ldx + ldx, d);
+#pragma unroll
+    for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], d[i]));
+    Vec<T>::store(out + ((n * Ho + oy) * Wo + ox) * ldo + c0, a);
+  }
+}
+
+// dx = (dskip ? dskip : 0) + scatter(dpool to the FIRST maximum of each window, row-major, as ATen does).
+// Folding the skip-connection gradient in here replaces autograd's separate accumulation pass.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dpool, int lddp,
+                                   const T* dskip, int ldds, T* dx, int lddx, int N, int H, int W, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E, Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  const long total = (long)N * Hc * Wc * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int c0 = (int)(r % ppp) * E; r /= ppp;
+    const int ox = (int)(r % Wc); r /= Wc;
+    const int oy = (int)(r % Hc);
+    const long n = r / Hc;
+    const bool pooled = oy < Ho && ox < Wo;
+    float g[E], v[4][E];
+    int arg[E];
+    if (pooled) {
+      Vec<T>::load(dpool + ((n * Ho + oy) * Wo + ox) * lddp + c0, g);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        Vec<T>::load(x + ((n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * ldx + c0, v[k]);
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        int a = 0;
+        float m = v[0][i];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+          if (v[k][i] > m) { m = v[k][i]; a = k; }
+        arg[i] = a;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+      if (yy >= H || xx >= W) continue;
+      const long off = (n * H + yy) * W + xx;
+      float o[E];
+      if (dskip) Vec<T>::load(dskip + off * ldds + c0, o);
+      else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) o[i] = 0.f;
+      }
+      if (pooled) {
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+          if (arg[i] == k) o[i] += g[i];
+      }
+      Vec<T>::store(dx + off * lddx + c0, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear x2, AC
+// unet_parts.py:50 + 59-67: Upsample(scale 2, bilinear, align_corners=True), F.pad to the skip size, and
+// placement into the concat buffer at a channel offset, in one pass: every pixel of the Hs x Ws destination
+// slice is written exactly once (zero outside the up-sampled window).
+__device__ __forceinline__ void ac_tap(int o, float scale, int n_in, int& i0, int& i1, float& f) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  f = src - (float)i0;
+}
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int h, int w,
+                                    int C, int Hs, int Ws, int padT, int padL) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+  const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  const long total = (long)N * Hs * Ws * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int c0 = (int)(r % ppp) * E; r /= ppp;
+    const int X = (int)(r % Ws); r /= Ws;
+    const int Y = (int)(r % Hs);
+    const long n = r / Hs;
+    const int oy = Y - padT, ox = X - padL;
+    float o[E];
+    if (oy >= 0 && oy < 2 * h && ox >= 0 && ox < 2 * w) {
+      int y0, y1, x0, x1;
+      float fy, fx;
+      ac_tap(oy, sy, h, y0, y1, fy);
+      ac_tap(ox, sx, w, x0, x1, fx);
+      float a[E], b[E], c[E], d[E];
+      const T* base = x + n * h * w * (long)ldx + c0;
+      Vec<T>::load(base + ((long)y0 * w + x0) * ldx, a);
+      Vec<T>::load(base + ((long)y0 * w + x1) * ldx, b);
+      Vec<T>::load(base + ((long)y1 * w + x0) * ldx, c);
+      Vec<T>::load(base + ((long)y1 * w + x1) * ldx, d);
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+        o[i] = (1.f - fy) * ((1.f - fx) * a[i] + fx * b[i]) + fy * ((1.f - fx) * c[i] + fx * d[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) o[i] = 0.f;
+    }
+    Vec<T>::store(out + ((n * Hs + Y) * Ws + X) * ldo + c0, o);
+  }
+}
+
+// gather form of the adjoint: every input pixel sums the destination pixels that sampled it
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dcat, int ldd, T* __restrict__ dx, int lddx, int N, int h,
+                                    int w, int C, int Hs, int Ws, int padT, int padL) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+  const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+  const long total = (long)N * h * w * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int c0 = (int)(r % ppp) * E; r /= ppp;
+    const int ix = (int)(r % w); r /= w;
+    const int iy = (int)(r % h);
+    const long n = r / h;
+    float acc[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[i] = 0.f;
+    for (int oy = max(0, 2 * iy - 2); oy <= min(2 * h - 1, 2 * iy + 4); ++oy) {
+      int y0, y1; float fy;
+      ac_tap(oy, sy, h, y0, y1, fy);
+      const float wy = (y0 == iy ? 1.f - fy : 0.f) + (y1 == iy ? fy : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = max(0, 2 * ix - 2); ox <= min(2 * w - 1, 2 * ix + 4); ++ox) {
+        int x0, x1; float fx;
+        ac_tap(ox, sx, w, x0, x1, fx);
+        const float wx = (x0 == ix ? 1.f - fx : 0.f) + (x1 == ix ? fx : 0.f);
+        if (wx == 0.f) continue;
+        float g[E];
+        Vec<T>::load(dcat + ((n * Hs + oy + padT) * Ws + ox + padL) * ldd + c0, g);
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] += wy * wx * g[i];
+      }
+    }
+    Vec<T>::store(dx + ((n * h + iy) * w + ix) * lddx + c0, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ slices
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const long total = npix * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx / ppp;
+    const int c0 = (int)(idx - pix * ppp) * E;
+    *reinterpret_cast<uint4*>(dst + pix * ldd + c0) = *reinterpret_cast<const uint4*>(src + pix * lds_ + c0);
+  }
+}
+
+// zero the F.pad border (unet_parts.py:62-63) of the up-sampled channel slice that convT does not write
+template <typename T>
+__global__ void zero_border_kernel(T* buf, int ld, int N, int Hs, int Ws, int C, int padT, int padL, int hu, int wu) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const long total = (long)N * Hs * Ws * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int c0 = (int)(r % ppp) * E; r /= ppp;
+    const int X = (int)(r % Ws); r /= Ws;
+    const int Y = (int)(r % Hs);
+    const long n = r / Hs;
+    if (Y >= padT && Y < padT + hu && X >= padL && X < padL + wu) continue;
+    *reinterpret_cast<uint4*>(buf + ((n * Hs + Y) * Ws + X) * ld + c0) = uint4{0u, 0u, 0u, 0u};
+  }
+}
+
+// ------------------------------------------------------------------------------------------ channel sums
+// out[c] = sum over a window of the image of x[n,y,x,c]   (bias gradient of ConvTranspose2d, unet_parts.py:53)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, int ld, int N, int Hs, int Ws, int C,
+                                                          int wy, int wx, int wh, int ww, double* sums) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[256 * E];
+  const int ppp = C / E;
+  const int pg = ppp < 256 ? ppp : 256;
+  const int lanes = 256 / pg;
+  const int piece_in_group = threadIdx.x % pg, plane = threadIdx.x / pg;
+  const int piece = blockIdx.y * 256 + piece_in_group;
+  const bool active = plane < lanes && piece < ppp;
+  for (int i = threadIdx.x; i < pg * E; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (active) {
+    float s[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) s[i] = 0.f;
+    const long npix = (long)N * wh * ww;
+    for (long q = (long)blockIdx.x * lanes + plane; q < npix; q += (long)gridDim.x * lanes) {
+      const int xx = (int)(q % ww);
+      const long r = q / ww;
+      const int yy = (int)(r % wh);
+      const long n = r / wh;
+      float v[E];
+      Vec<T>::load(x + ((n * Hs + wy + yy) * Ws + wx + xx) * ld + piece * E, v);
+#pragma unroll
+      for (int i = 0; i < E; ++i) s[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) atomicAdd(&red[piece_in_group * E + i], s[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < pg * E; i += 256)
+    if (blockIdx.y * 256 * E + i < C) unsafeAtomicAdd(sums + blockIdx.y * 256 * E + i, (double)red[i]);
+}
+
+__global__ void double_to_float_kernel(const double* in, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_act(const void* p, int ld, int c, int dtype) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4, e = 16 / es;
+  if (!p) return UNETK_ERR_ARG;
+  if (c <= 0 || c % e || ld < c) return UNETK_ERR_SHAPE;
+  if (!ok16(p) || (ld * es) % 16) return UNETK_ERR_ALIGN;
+  return UNETK_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                  \
+  if ((dtype) == UNETK_BF16) { using T = bf16; CALL; } else { using T = float; CALL; }
+
+extern "C" {
+
+int unetk_bn_train_finalize(const double* stats, int64_t count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float eps, float* scale, float* shift, float* mean, float* invstd, int c, void* stream) {
+  if (!stats || !scale || !shift || !mean || !invstd || c <= 0 || count <= 0) return UNETK_ERR_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return UNETK_ERR_ARG;
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats,
+                     (long)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps,
+                     scale, shift, mean, invstd, c);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, float* scale, float* shift, int c, void* stream) {
+  if (!running_mean || !running_var || !scale || !shift || c <= 0) return UNETK_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, c);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                        int64_t npix, int c, int dtype, void* stream) {
+  if (int e = check_act(y, ldy, c, dtype)) return e;
+  if (int e = check_act(out, ldo, c, dtype)) return e;
+  if (!scale || !shift || npix <= 0) return UNETK_ERR_ARG;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ew_grid(npix * (c / Vec<T>::E))), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (long)npix, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, double* sums, int64_t npix, int c, int dtype,
+                             void* stream) {
+  if (int e = check_act(dout, lddo, c, dtype)) return e;
+  if (int e = check_act(y, ldy, c, dtype)) return e;
+  if (!scale || !shift || !mean || !invstd || !sums || npix <= 0) return UNETK_ERR_ARG;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int ppp = c / e_;
+  const int pg = ppp < 256 ? ppp : 256;
+  if (256 % pg) return UNETK_ERR_SHAPE;   // channel counts are multiples of 64: pg is a power of two
+  const int lanes = 256 / pg;
+  long gx = (npix + lanes - 1) / lanes;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, (unsigned)((ppp + 255) / 256));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, invstd, sums,
+                                       (long)npix, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_finalize(const double* sums, int64_t count, const float* gamma, const float* invstd, float* dgamma,
+                               float* dbeta, float* coef, int c, void* stream) {
+  if (!sums || !invstd || !coef || c <= 0 || count <= 0) return UNETK_ERR_ARG;
+  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums,
+                     (long)count, gamma, invstd, dgamma, dbeta, coef, c);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,
+                            const float* mean, const float* coef, void* dy, int lddy, int64_t npix, int c, int dtype,
+                            void* stream) {
+  if (int e = check_act(dout, lddo, c, dtype)) return e;
+  if (int e = check_act(y, ldy, c, dtype)) return e;
+  if (int e = check_act(dy, lddy, c, dtype)) return e;
+  if (!scale || !shift || !mean || !coef || npix <= 0) return UNETK_ERR_ARG;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * (c / Vec<T>::E))), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean,
+                                       coef, (T*)dy, lddy, (long)npix, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_maxpool2x2_fwd(const void* x, int ldx, void* out, int ldo, int n, int h, int w, int c, int dtype,
+                         void* stream) {
+  if (int e = check_act(x, ldx, c, dtype)) return e;
+  if (int e = check_act(out, ldo, c, dtype)) return e;
+  if (n <= 0 || h < 2 || w < 2) return UNETK_ERR_SHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid((long)n * (h / 2) * (w / 2) * (c / Vec<T>::E))),
+                                       dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)out, ldo, n, h, w, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_maxpool2x2_bwd(const void* x, int ldx, const void* dpool, int lddp, const void* dskip, int ldds, void* dx,
+                         int lddx, int n, int h, int w, int c, int dtype, void* stream) {
+  if (int e = check_act(x, ldx, c, dtype)) return e;
+  if (int e = check_act(dpool, lddp, c, dtype)) return e;
+  if (int e = check_act(dx, lddx, c, dtype)) return e;
+  if (dskip)
+    if (int e = check_act(dskip, ldds, c, dtype)) return e;
+  if (n <= 0 || h < 2 || w < 2) return UNETK_ERR_SHAPE;
+  const long items = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)x, ldx, (const T*)dpool, lddp, (const T*)dskip, ldds, (T*)dx, lddx, n,
+                                       h, w, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bilinear2x_fwd(const void* x, int ldx, void* out, int ldo, int n, int h, int w, int c, int hs, int ws,
+                         int pad_t, int pad_l, int dtype, void* stream) {
+  if (int e = check_act(x, ldx, c, dtype)) return e;
+  if (int e = check_act(out, ldo, c, dtype)) return e;
+  if (n <= 0 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws)
+    return UNETK_ERR_SHAPE;
+  const long items = (long)n * hs * ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)x, ldx, (T*)out, ldo, n, h, w, c, hs, ws, pad_t, pad_l));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bilinear2x_bwd(const void* dcat, int ldd, void* dx, int lddx, int n, int h, int w, int c, int hs, int ws,
+                         int pad_t, int pad_l, int dtype, void* stream) {
+  if (int e = check_act(dcat, ldd, c, dtype)) return e;
+  if (int e = check_act(dx, lddx, c, dtype)) return e;
+  if (n <= 0 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws)
+    return UNETK_ERR_SHAPE;
+  const long items = (long)n * h * w * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dcat, ldd, (T*)dx, lddx, n, h, w, c, hs, ws, pad_t, pad_l));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_copy_channels(const void* src, int ld_src, void* dst, int ld_dst, int64_t npix, int c, int dtype,
+                        void* stream) {
+  if (int e = check_act(src, ld_src, c, dtype)) return e;
+  if (int e = check_act(dst, ld_dst, c, dtype)) return e;
+  if (npix <= 0) return UNETK_ERR_SHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(ew_grid(npix * (c / Vec<T>::E))), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)src, ld_src, (T*)dst, ld_dst, (long)npix, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int pad_t, int pad_l, int h_up, int w_up,
+                          int dtype, void* stream) {
+  if (int e = check_act(buf, ld, c, dtype)) return e;
+  if (n <= 0 || pad_t < 0 || pad_l < 0 || pad_t + h_up > hs || pad_l + w_up > ws) return UNETK_ERR_SHAPE;
+  if (h_up == hs && w_up == ws) return UNETK_OK;   // nothing to pad
+  const long items = (long)n * hs * ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(zero_border_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
+                                       (T*)buf, ld, n, hs, ws, c, pad_t, pad_l, h_up, w_up));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int win_y, int win_x, int win_h, int win_w,
+                      double* scratch, float* out, int dtype, void* stream) {
+  if (int e = check_act(x, ld, c, dtype)) return e;
+  if (!scratch || !out || n <= 0 || win_y < 0 || win_x < 0 || win_h <= 0 || win_w <= 0 || win_y + win_h > hs ||
+      win_x + win_w > ws)
+    return UNETK_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch, 0, (size_t)c * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int ppp = c / e_;
+  const int pg = ppp < 256 ? ppp : 256;
+  if (256 % pg) return UNETK_ERR_SHAPE;
+  const int lanes = 256 / pg;
+  long gx = ((long)n * win_h * win_w + lanes - 1) / lanes;
+  if (gx > 512) gx = 512;
+  dim3 grid((unsigned)gx, (unsigned)((ppp + 255) / 256));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, n, hs, ws, c,
+                                       win_y, win_x, win_h, win_w, scratch));
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(double_to_float_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)scratch, out, c);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

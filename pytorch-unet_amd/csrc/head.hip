@@ -1,0 +1,247 @@
+// OutConv: Conv2d(Cin -> n_classes, kernel 1) with bias (unet_parts.py:74).  n_classes is 1, 2 or 21 in the
+// reference's configurations, so this is an HBM-bound GEMV-like pass over the 64-channel feature map, not an
+// MFMA problem: it reads Cin*es bytes per pixel and writes n_classes*es.
+//
+// Lanes are laid out [pixel][16-byte piece] so that a wave reads 1 KiB contiguous per load; the pieces of one
+// pixel are summed with lane shuffles.  Classes are processed CT at a time (grid.y).
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void load_piece(const T* p, float* v) {
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
+  } else {
+    const f32x4 f = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f[i];
+  }
+}
+
+template <typename T> __device__ __forceinline__ void store_piece(T* p, const float* v) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
+    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, b);
+  } else {
+    f32x4 f = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f);
+  }
+}
+
+constexpr int CT = 4;   // classes per pass
+
+// G = lanes per pixel (power of two <= 64, <= pieces per pixel)
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, T* __restrict__ out, int ldo,
+                                                          long npix, int Cin, int ncls, int G) {
+  constexpr int E = ElemTraits<T>::E;
+  extern __shared__ float wl[];   // [CT][Cin]
+  const int cbase = blockIdx.y * CT;
+  for (int i = threadIdx.x; i < CT * Cin; i += 256) {
+    const int k = i / Cin;
+    wl[i] = (cbase + k < ncls) ? w[(size_t)(cbase + k) * Cin + (i - k * Cin)] : 0.f;
+  }
+  __syncthreads();
+  const int ppp = Cin / E;
+  const int sub = threadIdx.x % G, pl = threadIdx.x / G, lanes = 256 / G;
+  for (long pix0 = (long)blockIdx.x * lanes; pix0 < npix; pix0 += (long)gridDim.x * lanes) {
+    const long pix = pix0 + pl;
+    float acc[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) acc[k] = 0.f;
+    if (pix < npix) {
+      for (int p = sub; p < ppp; p += G) {
+        float v[E];
+        load_piece<T>(x + pix * ldx + p * E, v);
+#pragma unroll
+        for (int k = 0; k < CT; ++k)
+#pragma unroll
+          for (int i = 0; i < E; ++i) acc[k] = fmaf(v[i], wl[k * Cin + p * E + i], acc[k]);
+      }
+    }
+    for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < CT; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+    if (sub == 0 && pix < npix) {
+#pragma unroll
+      for (int k = 0; k < CT; ++k)
+        if (cbase + k < ncls) out[pix * ldo + cbase + k] = from_f32<T>(acc[k] + bias[cbase + k]);
+    }
+  }
+}
+
+// dx[pix][c] = sum_k dl[pix][k] * w[k][c]
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const T* __restrict__ dl, int lddl,
+                                                            const float* __restrict__ w, T* __restrict__ dx, int lddx,
+                                                            long npix, int Cin, int ncls) {
+  constexpr int E = ElemTraits<T>::E;
+  extern __shared__ float wl[];   // [ncls][Cin]
+  for (int i = threadIdx.x; i < ncls * Cin; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const int ppp = Cin / E;
+  const long total = npix * ppp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx / ppp;
+    const int c0 = (int)(idx - pix * ppp) * E;
+    float o[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) o[i] = 0.f;
+    for (int k = 0; k < ncls; ++k) {
+      const float g = to_f32(dl[pix * lddl + k]);
+#pragma unroll
+      for (int i = 0; i < E; ++i) o[i] = fmaf(g, wl[k * Cin + c0 + i], o[i]);
+    }
+    store_piece<T>(dx + pix * lddx + c0, o);
+  }
+}
+
+// per-block partials: slab[block][k][c] = sum over the block's pixels dl[pix][k]*x[pix][c]; column Cin = sum dl (bias)
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dl,
+                                                            int lddl, float* __restrict__ slab, long npix, int Cin,
+                                                            int ncls) {
+  constexpr int E = ElemTraits<T>::E;
+  extern __shared__ float red[];   // [CT][Cin + 1]
+  const int cbase = blockIdx.y * CT;
+  const int ppp = Cin / E;                  // host guarantees ppp divides 256
+  const int piece = threadIdx.x % ppp, pl = threadIdx.x / ppp, lanes = 256 / ppp;
+  for (int i = threadIdx.x; i < CT * (Cin + 1); i += 256) red[i] = 0.f;
+  __syncthreads();
+  float acc[CT][E], accb[CT];
+#pragma unroll
+  for (int k = 0; k < CT; ++k) {
+    accb[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[k][i] = 0.f;
+  }
+  for (long pix = (long)blockIdx.x * lanes + pl; pix < npix; pix += (long)gridDim.x * lanes) {
+    float v[E];
+    load_piece<T>(x + pix * ldx + piece * E, v);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      const float g = (cbase + k < ncls) ? to_f32(dl[pix * lddl + cbase + k]) : 0.f;
+      accb[k] += g;
+#pragma unroll
+      for (int i = 0; i < E; ++i) acc[k][i] = fmaf(g, v[i], acc[k][i]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CT; ++k) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) atomicAdd(&red[k * (Cin + 1) + piece * E + i], acc[k][i]);
+    if (piece == 0) atomicAdd(&red[k * (Cin + 1) + Cin], accb[k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CT * (Cin + 1); i += 256) {
+    const int k = i / (Cin + 1);
+    if (cbase + k < ncls) slab[((size_t)blockIdx.x * ncls + cbase + k) * (Cin + 1) + (i - k * (Cin + 1))] = red[i];
+  }
+}
+
+__global__ void conv1x1_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, float* dw, float* db, int Cin,
+                                            int ncls) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncls * (Cin + 1)) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * ncls * (Cin + 1) + idx];
+  const int k = idx / (Cin + 1), c = idx - k * (Cin + 1);
+  if (c < Cin) dw[k * Cin + c] = s;
+  else if (db) db[k] = s;
+}
+
+constexpr int kWgradBlocks = 512;
+
+int check_head(const void* x, int ldx, int cin, int ncls, int dtype) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4, e = 16 / es;
+  if (!x) return UNETK_ERR_ARG;
+  if (cin <= 0 || ncls <= 0 || cin % e || ldx < cin || (long)ncls * cin > 12288) return UNETK_ERR_SHAPE;
+  const int ppp = cin / e;
+  if (ppp > 256 || (256 % ppp)) return UNETK_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (ldx * es) % 16) return UNETK_ERR_ALIGN;
+  return UNETK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int unetk_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias, void* out, int ldo, int64_t npix,
+                      int c_in, int n_classes, int dtype, void* stream) {
+  if (int e = check_head(x, ldx, c_in, n_classes, dtype)) return e;
+  if (!w || !bias || !out || npix <= 0 || ldo < n_classes) return UNETK_ERR_ARG;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int ppp = c_in / e_;
+  int G = 1;
+  while (G * 2 <= ppp && G < 64) G *= 2;
+  const int lanes = 256 / G;
+  long gx = (npix + lanes - 1) / lanes;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, (unsigned)((n_classes + CT - 1) / CT));
+  const size_t lds = (size_t)CT * c_in * sizeof(float);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(conv1x1_fwd_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)x, ldx, w, bias,
+                       (bf16*)out, ldo, (long)npix, c_in, n_classes, G);
+  else
+    hipLaunchKernelGGL(conv1x1_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, ldx, w,
+                       bias, (float*)out, ldo, (long)npix, c_in, n_classes, G);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_conv1x1_dgrad(const void* dl, int lddl, const float* w, void* dx, int lddx, int64_t npix, int c_in,
+                        int n_classes, int dtype, void* stream) {
+  if (int e = check_head(dx, lddx, c_in, n_classes, dtype)) return e;
+  if (!w || !dl || npix <= 0 || lddl < n_classes) return UNETK_ERR_ARG;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  long g = (npix * (c_in / e_) + 255) / 256;
+  if (g > 2048) g = 2048;
+  const size_t lds = (size_t)n_classes * c_in * sizeof(float);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(conv1x1_dgrad_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16*)dl, lddl, w, (bf16*)dx, lddx, (long)npix, c_in, n_classes);
+  else
+    hipLaunchKernelGGL(conv1x1_dgrad_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const float*)dl, lddl, w, (float*)dx, lddx, (long)npix, c_in, n_classes);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int64_t unetk_conv1x1_wgrad_workspace_bytes(int c_in, int n_classes) {
+  if (c_in <= 0 || n_classes <= 0) return UNETK_ERR_SHAPE;
+  return (int64_t)kWgradBlocks * n_classes * (c_in + 1) * sizeof(float);
+}
+
+int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float* dw, float* db, void* workspace,
+                        int64_t workspace_bytes, int64_t npix, int c_in, int n_classes, int dtype, void* stream) {
+  if (int e = check_head(x, ldx, c_in, n_classes, dtype)) return e;
+  if (!dl || !dw || !workspace || npix <= 0 || lddl < n_classes) return UNETK_ERR_ARG;
+  if (workspace_bytes < unetk_conv1x1_wgrad_workspace_bytes(c_in, n_classes)) return UNETK_ERR_ARG;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int lanes = 256 / (c_in / e_);
+  long gx = (npix + lanes - 1) / lanes;
+  if (gx > kWgradBlocks) gx = kWgradBlocks;
+  dim3 grid((unsigned)gx, (unsigned)((n_classes + CT - 1) / CT));
+  const size_t lds = (size_t)CT * (c_in + 1) * sizeof(float);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes);
+  else
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, ldx,
+                       (const float*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes);
+  UNETK_CHECK_LAUNCH();
+  const int total = n_classes * (c_in + 1);
+  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, (int)gx, dw, db, c_in, n_classes);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

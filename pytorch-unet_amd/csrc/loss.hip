@@ -1,0 +1,265 @@
+// Segmentation loss of the reference's train step (train.py:81,102-111) and the dice helpers
+// (utils/dice_score.py:5-28) as wavefront reductions.
+//
+//   n_classes > 1 : mean CrossEntropy(logits, mask) + 1 - dice(softmax(logits), one_hot(mask))
+//   n_classes == 1: mean BCEWithLogits(z, mask)     + 1 - dice(sigmoid(z), mask)
+//
+// In both cases dice_loss() calls dice_coeff(..., reduce_batch_first=True) on a 3-D tensor, i.e. ONE global
+// ratio (2*sum(p*t) + eps) / (sum(p) + sum(t) + eps) over all N, C, H, W  (dice_score.py:10-16).
+// The forward reads each logit once and produces four fp64 sums; a 1-thread finalize turns them into the
+// scalar loss and the two coefficients the backward needs; the backward re-reads the logits once and writes
+// dlogits.  The eager reference takes ~10 kernels and several [N,C,H,W] fp32 temporaries for the same thing.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  // wave reduce
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+// sums[0] = sum CE (or BCE), sums[1] = sum p*t, sums[2] = sum p, sums[3] = sum t
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const T* __restrict__ z, int ldz,
+                                                           const long long* __restrict__ mask, long npix, int ncls,
+                                                           double* sums) {
+  __shared__ double sh[4];
+  double s_ce = 0, s_pt = 0, s_p = 0, s_t = 0;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+    const T* zp = z + pix * ldz;
+    const long long t = mask[pix];
+    if (ncls == 1) {
+      const float v = to_f32(zp[0]);
+      const float tf = (float)t;
+      const float p = 1.f / (1.f + __expf(-v));
+      s_ce += fmaxf(v, 0.f) - v * tf + log1pf(__expf(-fabsf(v)));
+      s_pt += p * tf;
+      s_p += p;
+      s_t += tf;
+    } else {
+      float m = -INFINITY;
+      for (int k = 0; k < ncls; ++k) m = fmaxf(m, to_f32(zp[k]));
+      float se = 0.f, zt = 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float v = to_f32(zp[k]);
+        se += __expf(v - m);
+        if (k == t) zt = v;
+      }
+      const bool valid = t >= 0 && t < ncls;
+      if (valid) {
+        s_ce += __logf(se) - (zt - m);
+        s_pt += __expf(zt - m) / se;
+        s_t += 1.0;
+      }
+      s_p += 1.0;   // softmax rows sum to one
+    }
+  }
+  s_ce = block_sum(s_ce, sh);
+  s_pt = block_sum(s_pt, sh);
+  s_p = block_sum(s_p, sh);
+  s_t = block_sum(s_t, sh);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(sums + 0, s_ce);
+    unsafeAtomicAdd(sums + 1, s_pt);
+    unsafeAtomicAdd(sums + 2, s_p);
+    unsafeAtomicAdd(sums + 3, s_t);
+  }
+}
+
+// out[0] = loss, out[1] = dice, out[2] = alpha, out[3] = beta  where d(1-dice)/dp = alpha*t + beta
+__global__ void seg_loss_finalize_kernel(const double* sums, long npix, float eps, float* out) {
+  const double inter = 2.0 * sums[1];
+  const double sets = sums[2] + sums[3];
+  double dice, alpha, beta;
+  if (sets == 0.0) {          // torch.where(sets_sum == 0, inter, sets_sum): ratio is identically 1
+    dice = (inter + eps) / (inter + eps);
+    alpha = 0.0;
+    beta = 0.0;
+  } else {
+    dice = (inter + eps) / (sets + eps);
+    alpha = -2.0 / (sets + eps);
+    beta = (inter + eps) / ((sets + eps) * (sets + eps));
+  }
+  out[0] = (float)(sums[0] / (double)npix + 1.0 - dice);
+  out[1] = (float)dice;
+  out[2] = (float)alpha;
+  out[3] = (float)beta;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const T* __restrict__ z, int ldz,
+                                                           const long long* __restrict__ mask, long npix, int ncls,
+                                                           const float* __restrict__ fin, const float* gout,
+                                                           T* __restrict__ dz, int lddz) {
+  const float go = gout ? *gout : 1.f;
+  const float alpha = fin[2], beta = fin[3];
+  const float inv_m = 1.f / (float)npix;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+    const T* zp = z + pix * ldz;
+    T* dp = dz + pix * lddz;
+    const long long t = mask[pix];
+    if (ncls == 1) {
+      const float v = to_f32(zp[0]);
+      const float tf = (float)t;
+      const float p = 1.f / (1.f + __expf(-v));
+      // d/dz [ BCE/M + (1 - dice) ] ;  d(1-dice)/dp = alpha*t + beta ; dp/dz = p(1-p)
+      dp[0] = from_f32<T>(go * ((p - tf) * inv_m + (alpha * tf + beta) * p * (1.f - p)));
+    } else {
+      float m = -INFINITY;
+      for (int k = 0; k < ncls; ++k) m = fmaxf(m, to_f32(zp[k]));
+      float se = 0.f, zt = 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float v = to_f32(zp[k]);
+        se += __expf(v - m);
+        if (k == t) zt = v;
+      }
+      const bool valid = t >= 0 && t < ncls;
+      const float inv = 1.f / se;
+      const float pt = valid ? __expf(zt - m) * inv : 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float p = __expf(to_f32(zp[k]) - m) * inv;
+        const float oh = (valid && k == t) ? 1.f : 0.f;
+        // CE: (p - onehot)/M ; dice through softmax: p_k * (g_k - sum_j p_j g_j), g = alpha*onehot + beta
+        const float g = (valid ? (p - oh) * inv_m : 0.f) + alpha * p * (oh - pt);
+        dp[k] = from_f32<T>(go * g);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dice_coeff
+// sums[g] = { sum x*t, sum x, sum t } over group g (a group = the dims dice_score.py:10 sums over)
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                        long group_size, double* sums) {
+  __shared__ double sh[4];
+  const long g = blockIdx.y;
+  const float* xg = x + g * group_size;
+  const float* tg = t + g * group_size;
+  double a = 0, b = 0, c = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < group_size; i += (long)gridDim.x * blockDim.x) {
+    const float xv = xg[i], tv = tg[i];
+    a += xv * tv;
+    b += xv;
+    c += tv;
+  }
+  a = block_sum(a, sh);
+  b = block_sum(b, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(sums + g * 3 + 0, a);
+    unsafeAtomicAdd(sums + g * 3 + 1, b);
+    unsafeAtomicAdd(sums + g * 3 + 2, c);
+  }
+}
+
+// dice = mean_g (2*I_g + eps) / (S_g + eps), S_g := (S_g == 0 ? 2*I_g : S_g);  coef[g] = {a_g, b_g} with
+// d dice / d x[g][i] = a_g * t + b_g
+__global__ void dice_finalize_kernel(const double* sums, int ngroups, float eps, float* dice_out, float* coef) {
+  double acc = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const double inter = 2.0 * sums[g * 3 + 0];
+    const double sets = sums[g * 3 + 1] + sums[g * 3 + 2];
+    if (sets == 0.0) {
+      acc += (inter + eps) / (inter + eps);
+      if (coef) { coef[g * 2] = 0.f; coef[g * 2 + 1] = 0.f; }
+    } else {
+      acc += (inter + eps) / (sets + eps);
+      if (coef) {
+        coef[g * 2] = (float)(2.0 / (sets + eps) / ngroups);
+        coef[g * 2 + 1] = (float)(-(inter + eps) / ((sets + eps) * (sets + eps)) / ngroups);
+      }
+    }
+  }
+  *dice_out = (float)(acc / ngroups);
+}
+
+__global__ void dice_bwd_kernel(const float* __restrict__ t, const float* __restrict__ coef, const float* gout,
+                                float sign, long group_size, float* __restrict__ dx) {
+  const long g = blockIdx.y;
+  const float go = (gout ? *gout : 1.f) * sign;
+  const float a = coef[g * 2] * go, b = coef[g * 2 + 1] * go;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < group_size; i += (long)gridDim.x * blockDim.x)
+    dx[g * group_size + i] = a * t[g * group_size + i] + b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int unetk_seg_loss_fwd(const void* logits, int ldz, const int64_t* mask, int64_t npix, int n_classes, float eps,
+                       double* sums4, float* out4, int dtype, void* stream) {
+  if (!logits || !mask || !sums4 || !out4 || npix <= 0 || n_classes <= 0 || ldz < n_classes) return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums4, 0, 4 * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
+  long g = (npix + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(seg_loss_fwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, s, (const bf16*)logits, ldz,
+                       (const long long*)mask, (long)npix, n_classes, sums4);
+  else
+    hipLaunchKernelGGL(seg_loss_fwd_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)logits, ldz,
+                       (const long long*)mask, (long)npix, n_classes, sums4);
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(1), 0, s, (const double*)sums4, (long)npix, eps, out4);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_seg_loss_bwd(const void* logits, int ldz, const int64_t* mask, int64_t npix, int n_classes,
+                       const float* out4, const float* grad_out, void* dlogits, int lddz, int dtype, void* stream) {
+  if (!logits || !mask || !out4 || !dlogits || npix <= 0 || n_classes <= 0 || ldz < n_classes || lddz < n_classes)
+    return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  long g = (npix + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(seg_loss_bwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                       (bf16*)dlogits, lddz);
+  else
+    hipLaunchKernelGGL(seg_loss_bwd_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                       (float*)dlogits, lddz);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_dice_fwd(const float* input, const float* target, int n_groups, int64_t group_size, float eps, double* sums,
+                   float* dice_out, float* coef, void* stream) {
+  if (!input || !target || !sums || !dice_out || n_groups <= 0 || n_groups > 65535 || group_size <= 0)
+    return UNETK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (size_t)n_groups * 3 * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
+  long gx = (group_size + 255) / 256;
+  const long cap = n_groups >= 2048 ? 1 : 2048 / n_groups;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, s, input, target,
+                     (long)group_size, sums);
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(1), 0, s, (const double*)sums, n_groups, eps, dice_out, coef);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out, float sign, int n_groups,
+                   int64_t group_size, float* dinput, void* stream) {
+  if (!target || !coef || !dinput || n_groups <= 0 || n_groups > 65535 || group_size <= 0) return UNETK_ERR_ARG;
+  long gx = (group_size + 255) / 256;
+  const long cap = n_groups >= 2048 ? 1 : 2048 / n_groups;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, (hipStream_t)stream, target,
+                     coef, grad_out, sign, (long)group_size, dinput);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,499 @@
+// Weight gradients of conv3x3 (unet_parts.py:16,19) and ConvTranspose2d k2 s2 (unet_parts.py:53) on MFMA.
+//
+//   dw[tap][r][c] = sum over pixels  A[pixel + tap][r] * B[pixel][c]
+//
+//   conv3x3 : A = layer input (rows r = ci, 9 taps served by SHIFTED reads of one halo tile in LDS),
+//             B = dy (cols c = co)
+//   convT   : A = dy of the up-sampled half, gathered with stride 2 per tap (rows r = co), B = x (cols c = ci)
+//
+// GEMM-K is the pixel index, which is the SLOW index of NHWC tensors, so both MFMA operands need a
+// transposed fragment: tiles are staged [pixel][64 channels] by LDS-DMA (global_load_lds, zero page for the
+// padding / ragged edge) and read with ds_read_b64_tr_b16 (cdna_hip_programming.md T10): 16 lanes fetch a
+// 4-pixel x 16-channel block and receive it channel-major.
+//
+// One workgroup = 4 waves as 2 (rows) x 2 (cols) of 32x32 MFMA blocks = a 64 x 64 channel tile, all taps
+// (9 x 16 accumulator registers per lane), and walks a contiguous range of 8x32-pixel tiles (split-K over
+// the grid).  Partial sums go to a [split][tap][row][col] fp32 slab; a second kernel adds the splits in a
+// fixed order (bitwise reproducible, no float atomics) and writes PyTorch's parameter layout.
+#include "common.h"
+
+namespace {
+
+__device__ uint4 g_zero_page[8];   // zero-initialised: source of padding for LDS-DMA
+
+struct WgradParams {
+  const bf16* a;      // tap-shifted operand
+  const bf16* b;      // fixed operand
+  float* slab;
+  int N, H, W;        // tile-grid domain (conv3: image; convT: low-res grid)
+  int Ca, Cb;         // channels of a (rows) and b (cols)
+  int lda, ldb;
+  int Ha, Wa;         // convT: dims of the image `a` lives in (the skip-sized concat gradient)
+  int padT, padL;
+  int tiles_x, tiles_y, ntiles, nsplit, row_tiles, col_tiles;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* lds0, const char* lds1) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)lds0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)lds1);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// swizzle of the 16-byte piece index inside a 128-byte pixel row: pixels p and p+2 (same 128-byte half of
+// a bank row) land in different 64-byte groups -> the 32-lane groups of the transposed read are conflict free
+__device__ __forceinline__ int swz(int p) { return ((p >> 1) & 1) << 2; }
+
+template <int MODE>   // 0 conv3x3, 1 convT2x2
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
+  constexpr int TAPS = MODE == 0 ? 9 : 4;
+  constexpr int APITCH = MODE == 0 ? 36 : 32;            // pixels per LDS row of the A tile (multiple of 4)
+  constexpr int AROWS = MODE == 0 ? 10 : 8;
+  constexpr int A_BYTES = 10 * 36 * 128;                 // region size (conv3 needs it all)
+  constexpr int A_INSTR = AROWS * APITCH * 8 / 64;       // 1-KiB LDS-DMA pieces per A tile
+  constexpr int B_INSTR = 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_a = smem;
+  char* lds_b = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 1, wj = wid & 1;
+
+  const int npairs = P.row_tiles * P.col_tiles;
+  const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+  const int rt = pair / P.col_tiles, ct = pair % P.col_tiles;
+  const int r0 = rt * 64, c0 = ct * 64;
+
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  // ---- per-lane transposed-read addresses (tile invariant)
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int sub = (pp & 1) * 8;
+  constexpr int NKW = MODE == 0 ? 3 : 1;
+  int addrA[NKW][2][2], addrB[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pb = ks * 16 + 8 * (g >> 1) + 4 * rd + q;
+#pragma unroll
+      for (int kw = 0; kw < NKW; ++kw) {
+        const int p = pb + kw;
+        const int c = wi * 4 + 2 * (g & 1) + (pp >> 1);
+        addrA[kw][ks][rd] = p * 128 + ((c ^ swz(p)) << 4) + sub;
+      }
+      const int cb = wj * 4 + 2 * (g & 1) + (pp >> 1);
+      addrB[ks][rd] = pb * 128 + ((cb ^ swz(pb)) << 4) + sub;
+    }
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int lp = lane >> 3, ls = lane & 7;    // pixel-in-piece, physical 16-byte slot
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx = tt % P.tiles_x; tt /= P.tiles_x;
+    const int ty = tt % P.tiles_y;
+    const int img = tt / P.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+
+    // B tile: 256 pixels x 64 channels of the un-shifted operand
+    const bf16* bimg = P.b + (size_t)img * P.H * P.W * P.ldb + c0;
+    auto issue_b = [&]() {
+#pragma unroll
+      for (int f = 0; f < B_INSTR / 4; ++f) {
+        const int fi = f * 4 + wid;
+        const int p = fi * 8 + lp;
+        const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+        const int c = ls ^ swz(p);
+        const char* src = zero;
+        if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(bimg + (size_t)(yy * P.W + xx) * P.ldb + c * 8);
+        glds16(src, lds_b + fi * 1024);
+      }
+    };
+    auto issue_a = [&](int tap) {
+      const bf16* aimg = P.a + (size_t)img * (MODE == 0 ? P.H * P.W : P.Ha * P.Wa) * P.lda + r0;
+#pragma unroll
+      for (int f = 0; f < (A_INSTR + 3) / 4; ++f) {
+        const int fi = f * 4 + wid;
+        if (fi < A_INSTR) {
+          const int p = fi * 8 + lp;
+          const int c = ls ^ swz(p);
+          const char* src = zero;
+          if constexpr (MODE == 0) {
+            const int hr = p / APITCH, hc = p - hr * APITCH;
+            const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+            if (hc < 34 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W)
+              src = reinterpret_cast<const char*>(aimg + (size_t)(yy * P.W + xx) * P.lda + c * 8);
+          } else {
+            const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+            if (yy < P.H && xx < P.W)
+              src = reinterpret_cast<const char*>(
+                  aimg + (size_t)((2 * yy + (tap >> 1) + P.padT) * P.Wa + 2 * xx + (tap & 1) + P.padL) * P.lda + c * 8);
+          }
+          glds16(src, lds_a + fi * 1024);
+        }
+      }
+    };
+
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // previous tile fully consumed
+    issue_b();
+    if constexpr (MODE == 0) {
+      issue_a(0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+      for (int tr = 0; tr < 8; ++tr) {
+        const char* arow = lds_a + tr * (APITCH * 128);
+        const char* brow = lds_b + tr * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const bf16x8 af = tr_read8(arow + kh * (APITCH * 128) + addrA[kw][ks][0],
+                                         arow + kh * (APITCH * 128) + addrA[kw][ks][1]);
+              acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[kh * 3 + kw], 0, 0, 0);
+            }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        if (tap > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_a(tap);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+        for (int tr = 0; tr < 8; ++tr) {
+          const char* arow = lds_a + tr * 4096;
+          const char* brow = lds_b + tr * 4096;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
+            const bf16x8 af = tr_read8(arow + addrA[0][ks][0], arow + addrA[0][ks][1]);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[tap], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial sums -> slab[split][tap][row][col]; C layout: col = lane&31, row = (i&3)+8*(i>>2)+4*(lane>>5)
+  const int j = lane & 31, h = lane >> 5;
+  float* out = P.slab + (size_t)split * TAPS * P.Ca * P.Cb;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      out[((size_t)t * P.Ca + row) * P.Cb + c0 + wj * 32 + j] = acc[t][i];
+    }
+}
+
+// out[row*s_row + col*s_col + tap] = sum_s slab[s][tap][row][col]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int taps,
+                                    int rows, int cols, long s_row, long s_col, int accumulate) {
+  const long total = (long)taps * rows * cols;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + idx];
+    const int col = (int)(idx % cols);
+    const long rem = idx / cols;
+    const int row = (int)(rem % rows);
+    const int tap = (int)(rem / rows);
+    float* o = out + row * s_row + col * s_col + tap;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ fp32 variant
+// Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A[i][k] one float per lane, k = lane>>5), no transpose needed: a lane
+// reads channel (lane&31) of pixel 2s + (lane>>5) with ds_read_b32 -- 32 consecutive floats per half-wave, conflict
+// free without a swizzle.  Tile = 32 x 32 channels (128-byte pixel rows, same LDS image sizes as bf16); the four
+// waves split the tile's pixel rows (2 each), keep all taps in registers and are summed through LDS at the end.
+struct WgradParamsF32 {
+  const float* a;
+  const float* b;
+  float* slab;
+  int N, H, W, Ca, Cb, lda, ldb, Ha, Wa, padT, padL;
+  int tiles_x, tiles_y, ntiles, nsplit, row_tiles, col_tiles;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(WgradParamsF32 P) {
+  constexpr int TAPS = MODE == 0 ? 9 : 4;
+  constexpr int APITCH = MODE == 0 ? 36 : 32;
+  constexpr int AROWS = MODE == 0 ? 10 : 8;
+  constexpr int A_BYTES = 10 * 36 * 128;
+  constexpr int A_INSTR = AROWS * APITCH * 8 / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_a = smem;
+  char* lds_b = smem + A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int npairs = P.row_tiles * P.col_tiles;
+  const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+  const int r0 = (pair / P.col_tiles) * 32, c0 = (pair % P.col_tiles) * 32;
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int lp = lane >> 3, ls = lane & 7;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int tt = tile;
+    const int tx = tt % P.tiles_x; tt /= P.tiles_x;
+    const int ty = tt % P.tiles_y;
+    const int img = tt / P.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+    const float* bimg = P.b + (size_t)img * P.H * P.W * P.ldb + c0;
+    const float* aimg = P.a + (size_t)img * (MODE == 0 ? P.H * P.W : P.Ha * P.Wa) * P.lda + r0;
+    auto issue_b = [&]() {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int fi = f * 4 + wid;
+        const int p = fi * 8 + lp;
+        const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+        const char* src = zero;
+        if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(bimg + (size_t)(yy * P.W + xx) * P.ldb + ls * 4);
+        glds16(src, lds_b + fi * 1024);
+      }
+    };
+    auto issue_a = [&](int tap) {
+#pragma unroll
+      for (int f = 0; f < (A_INSTR + 3) / 4; ++f) {
+        const int fi = f * 4 + wid;
+        if (fi < A_INSTR) {
+          const int p = fi * 8 + lp;
+          const char* src = zero;
+          if constexpr (MODE == 0) {
+            const int hr = p / APITCH, hc = p - hr * APITCH;
+            const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+            if (hc < 34 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W)
+              src = reinterpret_cast<const char*>(aimg + (size_t)(yy * P.W + xx) * P.lda + ls * 4);
+          } else {
+            const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+            if (yy < P.H && xx < P.W)
+              src = reinterpret_cast<const char*>(
+                  aimg + (size_t)((2 * yy + (tap >> 1) + P.padT) * P.Wa + 2 * xx + (tap & 1) + P.padL) * P.lda + ls * 4);
+          }
+          glds16(src, lds_a + fi * 1024);
+        }
+      }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_b();
+    if constexpr (MODE == 0) {
+      issue_a(0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * wid + rr;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+          const int px = 2 * s + h;
+          const float bv = *reinterpret_cast<const float*>(lds_b + (row * 32 + px) * 128 + r * 4);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float av = *reinterpret_cast<const float*>(lds_a + ((row + t / 3) * APITCH + px + t % 3) * 128 + r * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        if (tap > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_a(tap);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int row = 2 * wid + rr;
+#pragma unroll 4
+          for (int s = 0; s < 16; ++s) {
+            const int px = 2 * s + h;
+            const float bv = *reinterpret_cast<const float*>(lds_b + (row * 32 + px) * 128 + r * 4);
+            const float av = *reinterpret_cast<const float*>(lds_a + (row * 32 + px) * 128 + r * 4);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- sum the four waves through LDS, then one coalesced slab write
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* red = reinterpret_cast<float*>(smem);      // [TAPS][32][32]
+  for (int i = tid; i < TAPS * 1024; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) atomicAdd(&red[t * 1024 + ((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r], acc[t][i]);
+  __syncthreads();
+  float* out = P.slab + (size_t)split * TAPS * P.Ca * P.Cb;
+  for (int i = tid; i < TAPS * 1024; i += 256) {
+    const int t = i >> 10, row = (i >> 5) & 31, col = i & 31;
+    out[((size_t)t * P.Ca + r0 + row) * P.Cb + c0 + col] = red[i];
+  }
+}
+
+int pick_nsplit(int ntiles, int npairs) {
+  int ns = 512 / npairs;
+  if (ns < 1) ns = 1;
+  if (ns > ntiles) ns = ntiles;
+  return ns;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int c_out) {
+  if (n <= 0 || h <= 0 || w <= 0 || c_in % 64 || c_out % 64 || c_in <= 0 || c_out <= 0) return UNETK_ERR_SHAPE;
+  const int ntiles = n * host_cdiv(h, 8) * host_cdiv(w, 32);
+  const int npairs = (c_in / 64) * (c_out / 64);
+  const int taps = kind == 0 ? 9 : 4;
+  // bf16 uses 64x64 channel tiles, fp32 32x32 (4x the pairs, hence fewer splits): size for the larger (bf16) case
+  return (int64_t)pick_nsplit(ntiles, npairs) * taps * c_in * c_out * 4;
+}
+
+int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                        int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int accumulate, int dtype,
+                        void* stream) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int64_t need = unetk_wgrad_workspace_bytes(0, n, h, w, c_in, c_out);
+  if (need < 0) return (int)need;
+  if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
+  if (ldx < c_in || lddy < c_out || (ldx * es) % 16 || (lddy * es) % 16) return UNETK_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) return UNETK_ERR_ALIGN;
+  if (dtype == UNETK_F32) {
+    WgradParamsF32 Q{};
+    Q.a = (const float*)x; Q.b = (const float*)dy; Q.slab = (float*)workspace;
+    Q.N = n; Q.H = h; Q.W = w; Q.Ca = c_in; Q.Cb = c_out; Q.lda = ldx; Q.ldb = lddy;
+    Q.tiles_x = host_cdiv(w, 32); Q.tiles_y = host_cdiv(h, 8); Q.ntiles = n * Q.tiles_x * Q.tiles_y;
+    Q.row_tiles = c_in / 32; Q.col_tiles = c_out / 32;
+    Q.nsplit = pick_nsplit(Q.ntiles, Q.row_tiles * Q.col_tiles);
+    const size_t ldsq = 10 * 36 * 128 + 256 * 128;
+    static bool attr_q = false;
+    if (!attr_q) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess)
+        return UNETK_ERR_LAUNCH;
+      attr_q = true;
+    }
+    hipLaunchKernelGGL(wgrad_f32_kernel<0>, dim3(Q.row_tiles * Q.col_tiles * Q.nsplit), dim3(256), ldsq,
+                       (hipStream_t)stream, Q);
+    UNETK_CHECK_LAUNCH();
+    const long totalq = 9L * c_in * c_out;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((totalq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, Q.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
+  WgradParams P{};
+  P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
+  P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+  P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
+  P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
+  P.nsplit = pick_nsplit(P.ntiles, P.row_tiles * P.col_tiles);
+  const size_t lds = 10 * 36 * 128 + 256 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNETK_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_bf16_kernel<0>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
+                     (hipStream_t)stream, P);
+  UNETK_CHECK_LAUNCH();
+  const long total = 9L * c_in * c_out;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dw, P.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int dy_choff, float* dw, void* workspace,
+                         int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t,
+                         int pad_l, int accumulate, int dtype, void* stream) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int64_t need = unetk_wgrad_workspace_bytes(1, n, h, w, c_in, c_out);
+  if (need < 0) return (int)need;
+  if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
+  if (pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws) return UNETK_ERR_SHAPE;
+  if (ldx < c_in || lddy < dy_choff + c_out || (ldx * es) % 16 || (lddy * es) % 16 || (dy_choff * es) % 16)
+    return UNETK_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) return UNETK_ERR_ALIGN;
+  if (dtype == UNETK_F32) {
+    WgradParamsF32 Q{};
+    Q.a = (const float*)dy + dy_choff; Q.b = (const float*)x; Q.slab = (float*)workspace;
+    Q.N = n; Q.H = h; Q.W = w; Q.Ca = c_out; Q.Cb = c_in; Q.lda = lddy; Q.ldb = ldx;
+    Q.Ha = hs; Q.Wa = ws; Q.padT = pad_t; Q.padL = pad_l;
+    Q.tiles_x = host_cdiv(w, 32); Q.tiles_y = host_cdiv(h, 8); Q.ntiles = n * Q.tiles_x * Q.tiles_y;
+    Q.row_tiles = c_out / 32; Q.col_tiles = c_in / 32;
+    Q.nsplit = pick_nsplit(Q.ntiles, Q.row_tiles * Q.col_tiles);
+    const size_t ldsq = 10 * 36 * 128 + 256 * 128;
+    static bool attr_q = false;
+    if (!attr_q) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess)
+        return UNETK_ERR_LAUNCH;
+      attr_q = true;
+    }
+    hipLaunchKernelGGL(wgrad_f32_kernel<1>, dim3(Q.row_tiles * Q.col_tiles * Q.nsplit), dim3(256), ldsq,
+                       (hipStream_t)stream, Q);
+    UNETK_CHECK_LAUNCH();
+    const long totalq = 4L * c_in * c_out;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((totalq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, Q.nsplit, 4, c_out, c_in, 4L, (long)c_out * 4, accumulate);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
+  WgradParams P{};
+  P.a = (const bf16*)dy + dy_choff; P.b = (const bf16*)x; P.slab = (float*)workspace;
+  P.N = n; P.H = h; P.W = w; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
+  P.Ha = hs; P.Wa = ws; P.padT = pad_t; P.padL = pad_l;
+  P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
+  P.row_tiles = c_out / 64; P.col_tiles = c_in / 64;
+  P.nsplit = pick_nsplit(P.ntiles, P.row_tiles * P.col_tiles);
+  const size_t lds = 10 * 36 * 128 + 256 * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNETK_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
+                     (hipStream_t)stream, P);
+  UNETK_CHECK_LAUNCH();
+  // rows = co, cols = ci ; parameter layout [Ci][Co][2][2]
+  const long total = 4L * c_in * c_out;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dw, P.nsplit, 4, c_out, c_in, 4L, (long)c_out * 4, accumulate);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""UNet assembly with the reference's surface (unet/unet_model.py:6-48) on MI355X kernels.
+
+forward() runs the whole network as ONE autograd node (unetk.blocks composites): the four skip tensors are
+produced directly inside the decoder's concat buffers (no torch.cat copy, unet_parts.py:67), the gradient each
+skip receives from the decoder is folded into the max-pool backward kernel instead of a separate accumulation
+pass, and parameter gradients become available block by block in reverse order so a data-parallel trainer can
+bucket-all-reduce them while the rest of backward still runs (unetk.ddp).
+"""
+import torch
+import torch.nn as nn
+
+from unetk import blocks, ops
+from unetk.autograd import BlockFn
+from .unet_parts import DoubleConv, Down, Up, OutConv
+
+
+class _UNetImpl:
+    def __init__(self, net, dtype):
+        self.net, self.dtype = net, dtype
+
+    # ---- forward
+    def fwd(self, x):
+        net, dt = self.net, self.dtype
+        n, h, w, _, _ = ops.nhwc_meta(x, 'UNet input')
+        downs = [net.down1, net.down2, net.down3, net.down4]
+        ups = [net.up1, net.up2, net.up3, net.up4]
+        enc = [net.inc] + [d.maxpool_conv[1] for d in downs]
+        saved = {'enc': [], 'pool_in': [], 'up': [], 'dec': [], 'cats': []}
+        # encoder: level k's output is written straight into the first half of that level's concat buffer
+        cur, hh, ww = x, h, w
+        skips = []
+        for k, dc in enumerate(enc):
+            c_out = dc.double_conv[3].out_channels
+            if k < 4:
+                c_up = ups[3 - k].conv.double_conv[0].in_channels - c_out   # what the decoder's first conv expects
+                cat = ops.new_nhwc(n, hh, ww, c_out + c_up, dt, x.device)
+                out_view = cat[..., :c_out]
+            else:
+                cat, out_view = None, None
+            a, s = blocks.double_conv_fwd(dc, cur, dt, out=out_view)
+            saved['enc'].append(s)
+            if k < 4:
+                skips.append((cat, c_out))
+                saved['pool_in'].append(a)
+                if hh < 2 or ww < 2:
+                    raise RuntimeError('UNet: input too small for four 2x2 poolings')
+                cur = ops.maxpool_fwd(a)
+                hh, ww = hh // 2, ww // 2
+            else:
+                cur = a
+        # decoder
+        for k, up in enumerate(ups):
+            cat, c_skip = skips[3 - k]
+            saved['up'].append(blocks.up_into_cat(up.up, cur, cat, c_skip, dt))
+            cur, s = blocks.double_conv_fwd(up.conv, cat, dt)
+            saved['dec'].append(s)
+            saved['cats'].append(c_skip)
+        logits, hs = blocks.head_fwd(net.outc.conv, cur, dt)
+        saved['head'] = hs
+        return logits, saved
+
+    # ---- backward
+    def bwd(self, saved, dlogits, grads, needs):
+        net = self.net
+        downs = [net.down1, net.down2, net.down3, net.down4]
+        ups = [net.up1, net.up2, net.up3, net.up4]
+        enc = [net.inc] + [d.maxpool_conv[1] for d in downs]
+        ready = getattr(net, '_grad_ready_hook', None)
+
+        def done(params):
+            if ready is not None:
+                ready([p for p in params if p is not None], grads)
+
+        d = blocks.head_bwd(net.outc.conv, saved['head'], dlogits, grads, True)
+        done([net.outc.conv.weight, net.outc.conv.bias])
+        dcats = [None] * 4
+        for k in (3, 2, 1, 0):
+            up = ups[k]
+            dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True)
+            dcats[k] = dcat
+            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True)
+            done(blocks.up_params(up))
+        # encoder, deepest first; the skip gradient (first half of dcat) joins in the pool backward, in place
+        for k in (4, 3, 2, 1, 0):
+            need_dx = k > 0 or needs[0]
+            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx)
+            done(blocks.double_conv_params(enc[k]))
+            if k > 0:
+                dcat = dcats[4 - k]
+                c_skip = saved['cats'][4 - k]
+                dskip = dcat[..., :c_skip]
+                d = ops.maxpool_bwd(saved['pool_in'][k - 1], d, dskip, out=dskip)
+        return (d,)
+
+
+class UNet(nn.Module):
+    """reference unet_model.py:6-36: 5 encoder stages 64..1024/factor, 4 decoder stages, 1x1 head."""
+
+    def __init__(self, n_channels, n_classes, bilinear=False):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+        factor = 2 if bilinear else 1
+        self.inc = DoubleConv(n_channels, 64)
+        self.down1 = Down(64, 128)
+        self.down2 = Down(128, 256)
+        self.down3 = Down(256, 512)
+        self.down4 = Down(512, 1024 // factor)
+        self.up1 = Up(1024, 512 // factor, bilinear)
+        self.up2 = Up(512, 256 // factor, bilinear)
+        self.up3 = Up(256, 128 // factor, bilinear)
+        self.up4 = Up(128, 64, bilinear)
+        self.outc = OutConv(64, n_classes)
+
+    def hot_path_params(self):
+        """Parameters in the order the whole-network autograd node takes them."""
+        ps = blocks.double_conv_params(self.inc)
+        for d in (self.down1, self.down2, self.down3, self.down4):
+            ps += blocks.double_conv_params(d.maxpool_conv[1])
+        for u in (self.up1, self.up2, self.up3, self.up4):
+            ps += blocks.up_params(u)
+        return ps + [self.outc.conv.weight, self.outc.conv.bias]
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('the MI355X U-Net runs on the GPU only: move the input with .to("cuda") '
+                               '(there is no CPU fallback path)')
+        if x.dim() != 4 or x.shape[1] != self.n_channels:
+            raise RuntimeError(f'expected input [N, {self.n_channels}, H, W], got {tuple(x.shape)}')
+        impl = _UNetImpl(self, blocks.activation_dtype(x))
+        params = self.hot_path_params()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return BlockFn.apply(impl, 1, x, *params)
+        out, _ = impl.fwd(ops.to_nhwc(x))
+        return ops.to_nchw(out)
+
+    def use_checkpointing(self):
+        """reference unet_model.py:38-48 calls the *module* torch.utils.checkpoint and raises TypeError
+        (SURVEY.md 8a row A9), so its OOM fallback can never succeed.  Activation memory here is sized for
+        288 GB of HBM, so checkpointing is not needed; the method is kept for API compatibility
+        and fails the same way the reference does."""
+        raise TypeError("'module' object is not callable")

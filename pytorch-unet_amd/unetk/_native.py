@@ -23,26 +23,47 @@ if not os.path.exists(LIB_PATH):
                       '(or __graft_entry__.build()); there is no non-HIP fallback')
 lib = ctypes.CDLL(LIB_PATH)
 
-_vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), 'include', 'unetk.h')
+
+_CTYPE = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float}
 
 
-def _proto(name, argtypes, restype=_i):
-    fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
-    fn.argtypes = argtypes
-    fn.restype = restype
-    return fn
+def parse_header(path=HEADER_PATH):
+    """Read the `extern "C"` declarations of include/unetk.h -> {name: (argtypes, restype)}.
+
+    The header is the single source of truth for the ABI: the binding is generated from it, so a
+    signature change cannot silently desynchronise Python from the library."""
+    import re
+    text = open(path).read()
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    text = re.sub(r'^\s*#.*$', ' ', text, flags=re.M)
+    protos = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int64_t|int)\s+(unetk_\w+)\s*\(([^)]*)\)\s*;', text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPE[a.split()[-2] if len(a.split()) > 1 else a])
+        restype = ctypes.c_char_p if 'char' in ret else _CTYPE[ret]
+        protos[name] = (argtypes, restype)
+    return protos
 
 
-PROTOTYPES = {
-    'unetk_version': ([], _i),
-    'unetk_arch': ([], ctypes.c_char_p),
-    'unetk_packed_weight_bytes': ([_i, _i, _i, _i], _i64),
-    'unetk_pack_weight': ([_i, _vp, _vp, _i, _i, _i, _vp], _i),
-    'unetk_conv3x3_fprop': ([_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
-    'unetk_conv3x3_dgrad': ([_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp], _i),
-}
+PROTOTYPES = parse_header()
 
-fn = {k: _proto(k, a, r) for k, (a, r) in PROTOTYPES.items()}
+
+def _bind(name, argtypes, restype):
+    f = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
+    f.argtypes = argtypes
+    f.restype = restype
+    return f
+
+
+fn = {k: _bind(k, a, r) for k, (a, r) in PROTOTYPES.items()}
 
 
 def check(code, what):

@@ -1,0 +1,209 @@
+"""Forward/backward composites of the U-Net blocks on top of the HIP kernels (unetk.ops).
+
+Everything here works on NHWC views and explicit `saved` tuples; the nn.Modules in `unet/` wrap these in
+`torch.autograd.Function`s (per block for stand-alone use, one Function for the whole UNet so that the
+skip-connection buffers, the gradient accumulation of the skips and the gradient bucketing are under our control).
+
+Reference semantics restated (file:line into the reference):
+  double_conv_*   unet/unet_parts.py:15-22   conv3x3 -> BN -> ReLU, twice
+  pool            unet/unet_parts.py:34      MaxPool2d(2)
+  up_*            unet/unet_parts.py:49-67   Upsample|ConvTranspose2d -> F.pad -> cat([skip, up])
+  head_*          unet/unet_parts.py:74      Conv2d k=1 + bias
+"""
+import torch
+
+from . import ops
+
+
+def activation_dtype(x):
+    """bf16 under torch.autocast (the reference's --amp path, train.py:100), otherwise the input's dtype."""
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_gpu_dtype()
+        if dt != torch.bfloat16:
+            raise RuntimeError('the MI355X kernels implement bf16 and fp32; use torch.autocast(dtype=torch.bfloat16)')
+        return dt
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x.dtype
+    raise RuntimeError(f'unsupported activation dtype {x.dtype}')
+
+
+def packed_weight(mod, kind, dtype, c_out, c_in):
+    """Cached MFMA-fragment packing of mod.weight, refreshed when the parameter changes (optimizer step,
+    load_state_dict, .to())."""
+    w = mod.weight
+    cache = mod.__dict__.setdefault('_unetk_pack', {})
+    key = (kind, dtype)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr():
+        return hit[2]
+    t = ops.pack_weight(kind, w, c_out, c_in, dtype)
+    cache[key] = (w._version, w.data_ptr(), t)
+    return t
+
+
+def _f32c(p):
+    t = p.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _bn_uses_batch_stats(bn):
+    return bn.training or bn.running_mean is None
+
+
+def _check_bn(bn):
+    if bn.running_mean is not None and bn.running_mean.dtype != torch.float32:
+        raise RuntimeError('BatchNorm buffers must be fp32')
+    if bn.weight is not None and bn.weight.dtype != torch.float32:
+        raise RuntimeError('BatchNorm parameters must be fp32 (keep the model in fp32 and use autocast for bf16)')
+
+
+def conv_bn_relu_fwd(conv, bn, x, dtype, out=None):
+    """One conv3x3 -> BN -> ReLU.  x: NHWC view (fp32 image for the first layer, else `dtype`).
+    Returns (activation, saved) with saved = (x, y, state)."""
+    c_in, c_out = conv.in_channels, conv.out_channels
+    _check_bn(bn)
+    batch_stats = _bn_uses_batch_stats(bn)
+    n, h, w, _, _ = ops.nhwc_meta(x, 'conv input')
+    stats = ops.new_stats(c_out, x.device) if batch_stats else None
+    if c_in <= 4:
+        xin = x if x.dtype == torch.float32 else x.float()
+        y = ops.conv3x3_first_fprop(xin, _f32c(conv.weight), c_out, dtype, stats=stats)
+        x = xin
+    else:
+        if x.dtype != dtype:
+            x = x.to(dtype)
+        y = ops.conv3x3_fprop(x, packed_weight(conv, 0, dtype, c_out, c_in), c_out, stats=stats)
+    st = ops.BNState(c_out, x.device)
+    if batch_stats:
+        momentum = bn.momentum
+        update = bn.training and bn.running_mean is not None
+        if update and momentum is None:      # cumulative moving average (torch semantics)
+            momentum = 1.0 / float(int(bn.num_batches_tracked) + 1)
+
+        class _B:          # what the finalize kernel may touch
+            weight, bias = bn.weight, bn.bias
+            running_mean = bn.running_mean if update else None
+            running_var = bn.running_var if update else None
+            num_batches_tracked = bn.num_batches_tracked if update else None
+        ops.bn_train_finalize(stats, n * h * w, _B, st, float(momentum or 0.0), float(bn.eps))
+    else:
+        ops.bn_eval_params(bn, st, float(bn.eps))
+    act = ops.bn_relu_apply(y, st, out=out)
+    return act, (x, y, st)
+
+
+def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None):
+    """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing)."""
+    x, y, st = saved
+    c_in, c_out = conv.in_channels, conv.out_channels
+    if not _bn_uses_batch_stats(bn):
+        raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference trains in train mode)')
+    dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
+    dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta)
+    dw = _grad_buf(grads, conv.weight)
+    if c_in <= 4:
+        ops.conv3x3_first_wgrad(x, dy, dw)
+        if need_dx:
+            raise RuntimeError('gradient w.r.t. the input image is not implemented (the reference never needs it)')
+        return None
+    ops.conv3x3_wgrad(x, dy, dw)
+    if not need_dx:
+        return None
+    return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out)
+
+
+def _grad_buf(grads, p):
+    g = grads.get(p)
+    if g is None:
+        g = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        grads[p] = g
+    return g
+
+
+# ------------------------------------------------------------------------------------ DoubleConv
+def double_conv_fwd(dc, x, dtype, out=None):
+    seq = dc.double_conv
+    a1, s1 = conv_bn_relu_fwd(seq[0], seq[1], x, dtype)
+    a2, s2 = conv_bn_relu_fwd(seq[3], seq[4], a1, dtype, out=out)
+    return a2, (s1, s2)
+
+
+def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None):
+    seq = dc.double_conv
+    s1, s2 = saved
+    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True)
+    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out)
+
+
+def double_conv_params(dc):
+    seq = dc.double_conv
+    ps = [seq[0].weight, seq[1].weight, seq[1].bias, seq[3].weight, seq[4].weight, seq[4].bias]
+    return [p for p in ps if p is not None]
+
+
+# ------------------------------------------------------------------------------------ Up (both flavours)
+def pad_offsets(h, w, hs, ws):
+    """F.pad(x1, [dX//2, dX-dX//2, dY//2, dY-dY//2]) (unet_parts.py:59-63): top/left offsets of the window."""
+    dy, dx = hs - 2 * h, ws - 2 * w
+    if dy < 0 or dx < 0:
+        raise RuntimeError('Up: the skip tensor is smaller than the up-sampled one (negative padding is not supported)')
+    return dy // 2, dx // 2
+
+
+def up_into_cat(up_mod, x_low, cat, c_skip, dtype):
+    """Writes up(x_low), padded, into cat[..., c_skip:].  Returns saved info for backward."""
+    n, h, w, c_low, _ = ops.nhwc_meta(x_low, 'Up low-res input')
+    _, hs, ws, ctot, _ = ops.nhwc_meta(cat, 'Up concat buffer')
+    pad_t, pad_l = pad_offsets(h, w, hs, ws)
+    if x_low.dtype != dtype:
+        x_low = x_low.to(dtype)
+    if isinstance(up_mod, torch.nn.ConvTranspose2d):
+        c_out = up_mod.out_channels
+        if c_skip + c_out != ctot:
+            raise RuntimeError('Up: channel counts of skip and up-sampled tensors do not add up')
+        ops.convT2x2_fwd(x_low, packed_weight(up_mod, 2, dtype, c_out, c_low), _f32c(up_mod.bias), cat, c_skip, c_out,
+                         pad_t, pad_l)
+    else:
+        if c_skip + c_low != ctot:
+            raise RuntimeError('Up: channel counts of skip and up-sampled tensors do not add up')
+        ops.bilinear_fwd(x_low, cat, c_skip, pad_t, pad_l)
+    return (x_low, h, w, c_low, pad_t, pad_l)
+
+
+def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True):
+    x_low, h, w, c_low, pad_t, pad_l = saved
+    if isinstance(up_mod, torch.nn.ConvTranspose2d):
+        c_out = up_mod.out_channels
+        ops.convT2x2_wgrad(x_low, dcat, c_skip, _grad_buf(grads, up_mod.weight), _grad_buf(grads, up_mod.bias), pad_t, pad_l)
+        if not need_dx:
+            return None
+        return ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out, h, w,
+                                  pad_t, pad_l)
+    if not need_dx:
+        return None
+    return ops.bilinear_bwd(dcat, c_skip, c_low, h, w, pad_t, pad_l)
+
+
+def up_params(up_block):
+    ps = []
+    if isinstance(up_block.up, torch.nn.ConvTranspose2d):
+        ps += [up_block.up.weight, up_block.up.bias]
+    return ps + double_conv_params(up_block.conv)
+
+
+# ------------------------------------------------------------------------------------ head
+def head_fwd(conv, x, dtype):
+    if conv.kernel_size != (1, 1):
+        raise RuntimeError('OutConv expects a 1x1 convolution')
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    w = _f32c(conv.weight)
+    return ops.conv1x1_fwd(x, w, _f32c(conv.bias), conv.out_channels), (x, w)
+
+
+def head_bwd(conv, saved, dl, grads, need_dx=True):
+    x, w = saved
+    if dl.dtype != x.dtype:
+        dl = dl.to(x.dtype)
+    return ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), need_dx)

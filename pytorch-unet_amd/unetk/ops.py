@@ -11,13 +11,19 @@ from ._native import fn, check, dtype_code, stream_ptr, require_cuda
 
 
 def nhwc_meta(t, what='tensor'):
-    if t.dim() != 4 or t.stride(3) != 1:
-        raise RuntimeError(f'{what}: expected an NHWC view with unit channel stride, got shape {tuple(t.shape)} '
-                           f'strides {t.stride()}')
+    """(n, h, w, c, ld) of an NHWC view; strides of size-1 dimensions are don't-cares."""
+    if t.dim() != 4:
+        raise RuntimeError(f'{what}: expected a 4-D NHWC view, got shape {tuple(t.shape)}')
     n, h, w, c = t.shape
-    ld = t.stride(2) if w > 1 else max(c, t.stride(2))
-    if (h > 1 and t.stride(1) != w * ld) or (n > 1 and t.stride(0) != h * w * ld) or ld < c:
-        raise RuntimeError(f'{what}: rows/images must be dense (strides {t.stride()}, shape {tuple(t.shape)})')
+    sn, sh, sw, sc = t.stride()
+    ok = c == 1 or sc == 1
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    if w == 1 and h > 1:
+        ld = sh          # one pixel per row: the row stride is the pixel pitch
+    ok = ok and ld >= c and (h == 1 or w == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+    if not ok:
+        raise RuntimeError(f'{what}: expected a dense NHWC view with unit channel stride, got shape '
+                           f'{tuple(t.shape)} strides {t.stride()}')
     return n, h, w, c, ld
 
 
@@ -26,7 +32,16 @@ def new_nhwc(n, h, w, c, dtype, device):
 
 
 def to_nhwc(x):
-    """Logical NCHW (any strides) -> NHWC view; copies only if the memory is not channels_last."""
+    """Logical NCHW (any strides) -> NHWC view.  Free for channels_last tensors and for channel slices of
+    channels_last buffers; anything else is made channels_last first (a copy by PyTorch, outside the hot path)."""
+    v = x.permute(0, 2, 3, 1)
+    try:
+        _, _, _, c, ld = nhwc_meta(v)
+        es = x.element_size()
+        if (ld * es) % 16 == 0 and x.data_ptr() % 16 == 0:
+            return v
+    except RuntimeError:
+        pass
     return x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
 
 
@@ -87,3 +102,281 @@ def conv3x3_dgrad(dy, wpk_d, c_in, out=None):
     check(fn['unetk_conv3x3_dgrad'](dy.data_ptr(), lddy, 0, wpk_d.data_ptr(), out.data_ptr(), lddx, 0,
                                     n, h, w, c_in, c_out, dtype_code(dy.dtype), stream_ptr()), 'unetk_conv3x3_dgrad')
     return out
+
+
+# ------------------------------------------------------------------------------------ scratch
+_WS = {}
+
+
+def workspace(nbytes, device, tag='ws'):
+    """Per-(device, tag) grow-only scratch buffer (stream-ordered reuse on the current stream)."""
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------------------------ wgrad
+def conv3x3_wgrad(x, dy, dw):
+    """dw [Co,Ci,3,3] fp32 (written) from x [N,H,W,Ci] and dy [N,H,W,Co] (bf16)."""
+    require_cuda(x, dy, dw)
+    n, h, w, c_in, ldx = nhwc_meta(x, 'wgrad x')
+    n2, h2, w2, c_out, lddy = nhwc_meta(dy, 'wgrad dy')
+    if (n, h, w) != (n2, h2, w2) or tuple(dw.shape) != (c_out, c_in, 3, 3) or dw.dtype != torch.float32 \
+            or not dw.is_contiguous() or x.dtype != dy.dtype:
+        raise RuntimeError('conv3x3_wgrad: inconsistent arguments')
+    need = fn['unetk_wgrad_workspace_bytes'](0, n, h, w, c_in, c_out)
+    if need < 0:
+        check(int(need), 'unetk_wgrad_workspace_bytes')
+    ws = workspace(need, x.device)
+    check(fn['unetk_conv3x3_wgrad'](x.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    n, h, w, c_in, c_out, 0, dtype_code(x.dtype), stream_ptr()), 'unetk_conv3x3_wgrad')
+    return dw
+
+
+# ------------------------------------------------------------------------------------ first layer
+def conv3x3_first_fprop(x_f32, w_param, c_out, dtype, out=None, stats=None):
+    require_cuda(x_f32, w_param)
+    n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    if x_f32.dtype != torch.float32 or w_param.dtype != torch.float32 or not w_param.is_contiguous():
+        raise RuntimeError('first conv: image and parameter must be fp32')
+    if out is None:
+        out = new_nhwc(n, h, w, c_out, dtype, x_f32.device)
+    _, _, _, _, ldy = nhwc_meta(out, 'first conv output')
+    check(fn['unetk_conv3x3_first_fprop'](x_f32.data_ptr(), ldx, w_param.data_ptr(), out.data_ptr(), ldy, _ptr(stats),
+                                          n, h, w, c_in, c_out, dtype_code(dtype), stream_ptr()),
+          'unetk_conv3x3_first_fprop')
+    return out
+
+
+def conv3x3_first_wgrad(x_f32, dy, dw):
+    require_cuda(x_f32, dy, dw)
+    n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    _, _, _, c_out, lddy = nhwc_meta(dy, 'first conv dy')
+    need = fn['unetk_conv3x3_first_wgrad_workspace_bytes'](n, h, w, c_out)
+    if need < 0:
+        check(int(need), 'unetk_conv3x3_first_wgrad_workspace_bytes')
+    ws = workspace(need, dy.device)
+    check(fn['unetk_conv3x3_first_wgrad'](x_f32.data_ptr(), ldx, dy.data_ptr(), lddy, dw.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), n, h, w, c_in, c_out, dtype_code(dy.dtype), stream_ptr()),
+          'unetk_conv3x3_first_wgrad')
+    return dw
+
+
+# ------------------------------------------------------------------------------------ transposed conv (+pad+cat)
+def convT2x2_fwd(x, wpk, bias, cat, choff, c_out, pad_t, pad_l):
+    """Writes the up-sampled half into cat[..., choff:choff+c_out] and zeroes the F.pad border."""
+    require_cuda(x, wpk, bias, cat)
+    n, h, w, c_in, ldx = nhwc_meta(x, 'convT input')
+    n2, hs, ws_, ctot, ldc = nhwc_meta(cat, 'concat buffer')
+    dc = dtype_code(x.dtype)
+    up = cat[..., choff:choff + c_out]
+    check(fn['unetk_convT2x2_fwd'](x.data_ptr(), ldx, wpk.data_ptr(), bias.data_ptr(), cat.data_ptr(), ldc, choff,
+                                   n, h, w, c_in, c_out, hs, ws_, pad_t, pad_l, dc, stream_ptr()), 'unetk_convT2x2_fwd')
+    check(fn['unetk_zero_pad_border'](up.data_ptr(), ldc, n, hs, ws_, c_out, pad_t, pad_l, 2 * h, 2 * w, dc,
+                                      stream_ptr()), 'unetk_zero_pad_border')
+
+
+def convT2x2_dgrad(dcat, choff, wpk_d, c_in, c_out, h, w, pad_t, pad_l):
+    require_cuda(dcat, wpk_d)
+    n, hs, ws_, ctot, ldd = nhwc_meta(dcat, 'concat gradient')
+    dx = new_nhwc(n, h, w, c_in, dcat.dtype, dcat.device)
+    check(fn['unetk_convT2x2_dgrad'](dcat.data_ptr(), ldd, choff, wpk_d.data_ptr(), dx.data_ptr(), c_in, n, h, w, c_in,
+                                     c_out, hs, ws_, pad_t, pad_l, dtype_code(dcat.dtype), stream_ptr()),
+          'unetk_convT2x2_dgrad')
+    return dx
+
+
+def convT2x2_wgrad(x, dcat, choff, dw, db, pad_t, pad_l):
+    require_cuda(x, dcat, dw, db)
+    n, h, w, c_in, ldx = nhwc_meta(x, 'convT input')
+    _, hs, ws_, ctot, ldd = nhwc_meta(dcat, 'concat gradient')
+    c_out = dw.shape[1]
+    dc = dtype_code(x.dtype)
+    need = fn['unetk_wgrad_workspace_bytes'](1, n, h, w, c_in, c_out)
+    if need < 0:
+        check(int(need), 'unetk_wgrad_workspace_bytes')
+    ws = workspace(need, x.device)
+    check(fn['unetk_convT2x2_wgrad'](x.data_ptr(), ldx, dcat.data_ptr(), ldd, choff, dw.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), n, h, w, c_in, c_out, hs, ws_, pad_t, pad_l, 0, dc, stream_ptr()),
+          'unetk_convT2x2_wgrad')
+    up = dcat[..., choff:choff + c_out]
+    scratch = workspace(c_out * 8, x.device, 'chsum')
+    check(fn['unetk_channel_sum'](up.data_ptr(), ldd, n, hs, ws_, c_out, pad_t, pad_l, 2 * h, 2 * w, scratch.data_ptr(),
+                                  db.data_ptr(), dc, stream_ptr()), 'unetk_channel_sum')
+
+
+# ------------------------------------------------------------------------------------ BN + ReLU
+class BNState:
+    """Per-layer scale/shift (+ mean/invstd in train mode): [4, C] fp32."""
+
+    def __init__(self, c, device):
+        self.buf = torch.empty((4, c), dtype=torch.float32, device=device)
+        self.scale, self.shift, self.mean, self.invstd = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
+
+
+def bn_train_finalize(stats, count, bn, state, momentum, eps):
+    c = state.scale.numel()
+    check(fn['unetk_bn_train_finalize'](stats.data_ptr(), count, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                                        _ptr(bn.running_var), _ptr(bn.num_batches_tracked), momentum, eps,
+                                        state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                        state.invstd.data_ptr(), c, stream_ptr()), 'unetk_bn_train_finalize')
+
+
+def bn_eval_params(bn, state, eps):
+    c = state.scale.numel()
+    check(fn['unetk_bn_eval_params'](_ptr(bn.weight), _ptr(bn.bias), bn.running_mean.data_ptr(),
+                                     bn.running_var.data_ptr(), eps, state.scale.data_ptr(), state.shift.data_ptr(), c,
+                                     stream_ptr()), 'unetk_bn_eval_params')
+
+
+def bn_relu_apply(y, state, out=None):
+    n, h, w, c, ldy = nhwc_meta(y, 'bn input')
+    if out is None:
+        out = new_nhwc(n, h, w, c, y.dtype, y.device)
+    _, _, _, _, ldo = nhwc_meta(out, 'bn output')
+    check(fn['unetk_bn_relu_apply'](y.data_ptr(), ldy, state.scale.data_ptr(), state.shift.data_ptr(), out.data_ptr(),
+                                    ldo, n * h * w, c, dtype_code(y.dtype), stream_ptr()), 'unetk_bn_relu_apply')
+    return out
+
+
+def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None):
+    """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C])."""
+    n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
+    _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
+    dc = dtype_code(y.dtype)
+    npix = n * h * w
+    sums = new_stats(c, y.device)
+    coef = torch.empty((3, c), dtype=torch.float32, device=y.device)
+    check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
+                                         state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
+                                         sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
+    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
+                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+    if out is None:
+        out = new_nhwc(n, h, w, c, y.dtype, y.device)
+    _, _, _, _, ldo = nhwc_meta(out, 'bn grad output')
+    check(fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
+                                        state.shift.data_ptr(), state.mean.data_ptr(), coef.data_ptr(), out.data_ptr(),
+                                        ldo, npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_apply')
+    return out
+
+
+# ------------------------------------------------------------------------------------ max pool
+def maxpool_fwd(x):
+    n, h, w, c, ldx = nhwc_meta(x, 'pool input')
+    out = new_nhwc(n, h // 2, w // 2, c, x.dtype, x.device)
+    check(fn['unetk_maxpool2x2_fwd'](x.data_ptr(), ldx, out.data_ptr(), c, n, h, w, c, dtype_code(x.dtype),
+                                     stream_ptr()), 'unetk_maxpool2x2_fwd')
+    return out
+
+
+def maxpool_bwd(x, dpool, dskip=None, out=None):
+    n, h, w, c, ldx = nhwc_meta(x, 'pool input')
+    _, _, _, _, lddp = nhwc_meta(dpool, 'pool grad')
+    ldds = 0
+    if dskip is not None:
+        _, _, _, _, ldds = nhwc_meta(dskip, 'skip grad')
+    if out is None:
+        out = new_nhwc(n, h, w, c, x.dtype, x.device)
+    _, _, _, _, lddx = nhwc_meta(out, 'pool dx')
+    check(fn['unetk_maxpool2x2_bwd'](x.data_ptr(), ldx, dpool.data_ptr(), lddp, _ptr(dskip), ldds, out.data_ptr(), lddx,
+                                     n, h, w, c, dtype_code(x.dtype), stream_ptr()), 'unetk_maxpool2x2_bwd')
+    return out
+
+
+# ------------------------------------------------------------------------------------ bilinear (+pad+cat)
+def bilinear_fwd(x, cat, choff, pad_t, pad_l):
+    n, h, w, c, ldx = nhwc_meta(x, 'upsample input')
+    _, hs, ws_, _, ldc = nhwc_meta(cat, 'concat buffer')
+    up = cat[..., choff:choff + c]
+    check(fn['unetk_bilinear2x_fwd'](x.data_ptr(), ldx, up.data_ptr(), ldc, n, h, w, c, hs, ws_, pad_t, pad_l,
+                                     dtype_code(x.dtype), stream_ptr()), 'unetk_bilinear2x_fwd')
+
+
+def bilinear_bwd(dcat, choff, c, h, w, pad_t, pad_l):
+    n, hs, ws_, _, ldd = nhwc_meta(dcat, 'concat gradient')
+    dx = new_nhwc(n, h, w, c, dcat.dtype, dcat.device)
+    up = dcat[..., choff:choff + c]
+    check(fn['unetk_bilinear2x_bwd'](up.data_ptr(), ldd, dx.data_ptr(), c, n, h, w, c, hs, ws_, pad_t, pad_l,
+                                     dtype_code(dcat.dtype), stream_ptr()), 'unetk_bilinear2x_bwd')
+    return dx
+
+
+def copy_channels(src, dst):
+    n, h, w, c, lds = nhwc_meta(src, 'copy src')
+    n2, h2, w2, c2, ldd = nhwc_meta(dst, 'copy dst')
+    if (n, h, w, c) != (n2, h2, w2, c2) or src.dtype != dst.dtype:
+        raise RuntimeError('copy_channels: shape/dtype mismatch')
+    check(fn['unetk_copy_channels'](src.data_ptr(), lds, dst.data_ptr(), ldd, n * h * w, c, dtype_code(src.dtype),
+                                    stream_ptr()), 'unetk_copy_channels')
+
+
+# ------------------------------------------------------------------------------------ 1x1 head
+def conv1x1_fwd(x, w_param, bias, n_classes):
+    n, h, w, c, ldx = nhwc_meta(x, 'head input')
+    out = new_nhwc(n, h, w, n_classes, x.dtype, x.device)
+    check(fn['unetk_conv1x1_fwd'](x.data_ptr(), ldx, w_param.data_ptr(), bias.data_ptr(), out.data_ptr(), n_classes,
+                                  n * h * w, c, n_classes, dtype_code(x.dtype), stream_ptr()), 'unetk_conv1x1_fwd')
+    return out
+
+
+def conv1x1_bwd(x, dl, w_param, dw, db, need_dx=True):
+    n, h, w, c, ldx = nhwc_meta(x, 'head input')
+    _, _, _, ncls, lddl = nhwc_meta(dl, 'head grad')
+    dc = dtype_code(x.dtype)
+    npix = n * h * w
+    need = fn['unetk_conv1x1_wgrad_workspace_bytes'](c, ncls)
+    ws = workspace(need, x.device)
+    check(fn['unetk_conv1x1_wgrad'](x.data_ptr(), ldx, dl.data_ptr(), lddl, dw.data_ptr(), _ptr(db), ws.data_ptr(),
+                                    ws.numel(), npix, c, ncls, dc, stream_ptr()), 'unetk_conv1x1_wgrad')
+    dx = None
+    if need_dx:
+        dx = new_nhwc(n, h, w, c, x.dtype, x.device)
+        check(fn['unetk_conv1x1_dgrad'](dl.data_ptr(), lddl, w_param.data_ptr(), dx.data_ptr(), c, npix, c, ncls, dc,
+                                        stream_ptr()), 'unetk_conv1x1_dgrad')
+    return dx
+
+
+# ------------------------------------------------------------------------------------ loss
+def seg_loss_fwd(logits, mask, eps=1e-6):
+    """logits NHWC [N,H,W,C]; mask int64 [N,H,W].  Returns out4 = {loss, dice, alpha, beta} (device floats)."""
+    n, h, w, c, ldz = nhwc_meta(logits, 'logits')
+    if mask.dtype != torch.int64 or not mask.is_contiguous() or mask.numel() != n * h * w:
+        raise RuntimeError('seg_loss: mask must be a contiguous int64 [N,H,W] tensor')
+    sums = torch.empty(4, dtype=torch.float64, device=logits.device)
+    out4 = torch.empty(4, dtype=torch.float32, device=logits.device)
+    check(fn['unetk_seg_loss_fwd'](logits.data_ptr(), ldz, mask.data_ptr(), n * h * w, c, eps, sums.data_ptr(),
+                                   out4.data_ptr(), dtype_code(logits.dtype), stream_ptr()), 'unetk_seg_loss_fwd')
+    return out4
+
+
+def seg_loss_bwd(logits, mask, out4, grad_out=None):
+    n, h, w, c, ldz = nhwc_meta(logits, 'logits')
+    dl = new_nhwc(n, h, w, c, logits.dtype, logits.device)
+    check(fn['unetk_seg_loss_bwd'](logits.data_ptr(), ldz, mask.data_ptr(), n * h * w, c, out4.data_ptr(),
+                                   _ptr(grad_out), dl.data_ptr(), c, dtype_code(logits.dtype), stream_ptr()),
+          'unetk_seg_loss_bwd')
+    return dl
+
+
+def dice_fwd(inp, tgt, n_groups, group_size, eps, need_coef):
+    sums = torch.empty(n_groups * 3, dtype=torch.float64, device=inp.device)
+    out = torch.empty(1, dtype=torch.float32, device=inp.device)
+    coef = torch.empty(n_groups * 2, dtype=torch.float32, device=inp.device) if need_coef else None
+    check(fn['unetk_dice_fwd'](inp.data_ptr(), tgt.data_ptr(), n_groups, group_size, eps, sums.data_ptr(),
+                               out.data_ptr(), _ptr(coef), stream_ptr()), 'unetk_dice_fwd')
+    return out, coef
+
+
+def dice_bwd(tgt, coef, grad_out, sign, n_groups, group_size):
+    dx = torch.empty(n_groups * group_size, dtype=torch.float32, device=tgt.device)
+    check(fn['unetk_dice_bwd'](tgt.data_ptr(), coef.data_ptr(), _ptr(grad_out), sign, n_groups, group_size,
+                               dx.data_ptr(), stream_ptr()), 'unetk_dice_bwd')
+    return dx

@@ -31,3 +31,8 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# whole-network golden cases (tag, n_classes, bilinear, input shape): keep in sync with oracle/make_golden.py
+UNET_CASES = [('unet_c2_convT', 2, False, (2, 3, 96, 142)), ('unet_c2_bilinear', 2, True, (2, 3, 96, 142)),
+              ('unet_c21_convT', 21, False, (2, 3, 64, 80)), ('unet_c1_convT', 1, False, (2, 3, 112, 99))]

