@@ -66,6 +66,9 @@ class _UNetImpl:
         ups = [net.up1, net.up2, net.up3, net.up4]
         enc = [net.inc] + [d.maxpool_conv[1] for d in downs]
         ready = getattr(net, '_grad_ready_hook', None)
+        init = getattr(net, '_initial_grads', None)
+        if init is not None:
+            grads.update(init())          # gradients land in one flat, bucket-ordered buffer (unetk.ddp)
 
         def done(params):
             if ready is not None:

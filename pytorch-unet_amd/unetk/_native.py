@@ -87,3 +87,63 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError('unetk kernels run on the GPU only (no CPU fallback); got a CPU tensor')
+
+
+# ---------------------------------------------------------------------------------------------- kernel timing
+class KernelTimer:
+    """Brackets every C-ABI launch with HIP events on the stream it is launched on (torch's current stream) and
+    attributes algorithmic FLOPs to the MFMA convolutions.  Used by bench.py for the `roofline` object; off by
+    default (zero overhead: the dict holds the raw ctypes functions)."""
+
+    def __init__(self):
+        self.records = []      # (name, start_event, end_event, flops)
+        self._saved = None
+
+    @staticmethod
+    def _flops(name, a):
+        # argument positions follow include/unetk.h
+        if name == 'unetk_conv3x3_fprop':
+            return 2.0 * a[8] * a[9] * a[10] * 9 * a[11] * a[12]
+        if name == 'unetk_conv3x3_dgrad':
+            return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
+        if name == 'unetk_conv3x3_wgrad':
+            return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
+        if name == 'unetk_conv3x3_first_fprop':
+            return 2.0 * a[6] * a[7] * a[8] * 9 * a[9] * a[10]
+        if name == 'unetk_conv3x3_first_wgrad':
+            return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
+        if name == 'unetk_convT2x2_fwd':
+            return 2.0 * a[7] * a[8] * a[9] * 4 * a[10] * a[11]
+        if name == 'unetk_convT2x2_dgrad':
+            return 2.0 * a[6] * a[7] * a[8] * 4 * a[9] * a[10]
+        if name == 'unetk_convT2x2_wgrad':
+            return 2.0 * a[8] * a[9] * a[10] * 4 * a[11] * a[12]
+        return 0.0
+
+    def __enter__(self):
+        self._saved = dict(fn)
+        for name, raw in self._saved.items():
+            if PROTOTYPES[name][1] is not ctypes.c_int or not PROTOTYPES[name][0]:
+                continue
+
+            def timed(*args, _raw=raw, _name=name):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = _raw(*args)
+                e.record()
+                self.records.append((_name, s, e, self._flops(_name, args)))
+                return rc
+            fn[name] = timed
+        return self
+
+    def __exit__(self, *exc):
+        fn.update(self._saved)
+        return False
+
+    def summary(self):
+        """{name: (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for name, s, e, fl in self.records:
+            n, ms, f = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, ms + s.elapsed_time(e), f + fl)
+        return out

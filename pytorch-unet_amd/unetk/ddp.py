@@ -1,0 +1,77 @@
+"""Gradient bucketing for the data-parallel train step (the reference itself has no distributed code).
+
+One process per GPU.  The whole-network autograd node (unet/unet_model.py) reports each block's parameters as
+soon as their gradients are final, in reverse execution order (outc, up4 ... up1, down4 ... inc).  FlatGrads lays
+all parameter gradients out in ONE fp32 buffer in exactly that order, so "the gradients finished so far" is always
+a contiguous range; whenever >= bucket_bytes are pending, that range is all-reduced (average) asynchronously on
+RCCL's stream while the remaining backward kernels keep the compute stream busy.  BatchNorm buffers are not
+touched: statistics stay per rank (north_star).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGrads:
+    def __init__(self, net, process_group=None, bucket_bytes=25 << 20):
+        self.params = list(reversed(net.hot_path_params()))   # approximate completion order; ranges are re-derived
+        order = []
+        for blk in self._completion_blocks(net):
+            order += blk
+        assert len(order) == len(self.params) and len(set(map(id, order))) == len(order)
+        self.params = order
+        self.offsets, off = {}, 0
+        for p in order:
+            self.offsets[id(p)] = off
+            off += (p.numel() + 3) // 4 * 4                   # keep every view 16-byte aligned
+        self.total = off
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        self.flat = None
+        self._pending = [0, 0]
+        self._works = []
+        net._grad_ready_hook = self.ready
+        net._initial_grads = self.initial_grads
+
+    @staticmethod
+    def _completion_blocks(net):
+        from . import blocks
+        out = [[net.outc.conv.weight, net.outc.conv.bias]]
+        for u in (net.up4, net.up3, net.up2, net.up1):
+            out.append(blocks.up_params(u))
+        for d in (net.down4, net.down3, net.down2, net.down1):
+            out.append(blocks.double_conv_params(d.maxpool_conv[1]))
+        out.append(blocks.double_conv_params(net.inc))
+        return out
+
+    def initial_grads(self):
+        """Fresh flat buffer + per-parameter views for one backward pass."""
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)   # zero: alignment gaps enter the norm
+        self._pending = [0, 0]
+        self._works = []
+        return {p: self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape) for p in self.params}
+
+    def ready(self, params, grads):
+        if not params:
+            return
+        lo = min(self.offsets[id(p)] for p in params)
+        hi = max(self.offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in params)
+        assert lo == self._pending[1], 'blocks must complete in layout order'
+        self._pending[1] = hi
+        if self.world > 1 and hi - self._pending[0] >= self.bucket_elems:
+            self._launch()
+
+    def _launch(self):
+        lo, hi = self._pending
+        if hi > lo:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        self._pending = [hi, hi]
+
+    def finish(self):
+        """Call after backward(): flush the last bucket and make the compute stream wait for every all-reduce."""
+        if self.world > 1:
+            self._launch()
+            for w in self._works:
+                w.wait()
+        self._works = []

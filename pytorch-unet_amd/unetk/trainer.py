@@ -1,0 +1,43 @@
+"""The reference's inner training step (train.py:77-81, 97-117) on the MI355X kernels, data-parallel.
+
+  images -> channels_last fp32 ; autocast(bf16) forward ; CE/BCE + dice ; zero_grad(set_to_none) ; backward
+  (gradient buckets all-reduced over RCCL while backward runs) ; clip_grad_norm_(1.0) ; RMSprop(lr 1e-5,
+  weight_decay 1e-8, momentum 0.999, foreach) step.
+
+The reference's GradScaler (train.py:80,114-117) exists for fp16; BASELINE.json's configurations are bf16, whose
+range needs no loss scaling, so no scaler is used.  The optimizer step stays in PyTorch (foreach) for now
+(SURVEY.md 8f row 2); the clip is applied to the single flat gradient buffer (same arithmetic as
+torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1).
+"""
+import torch
+
+from .ddp import FlatGrads
+from .loss import segmentation_loss
+
+
+class Trainer:
+    def __init__(self, net, learning_rate=1e-5, weight_decay=1e-8, momentum=0.999, gradient_clipping=1.0, amp=True,
+                 process_group=None, bucket_bytes=25 << 20):
+        self.net = net
+        self.amp = amp
+        self.clip = gradient_clipping
+        self.optimizer = torch.optim.RMSprop(net.parameters(), lr=learning_rate, weight_decay=weight_decay,
+                                             momentum=momentum, foreach=True)
+        self.sync = FlatGrads(net, process_group, bucket_bytes)
+
+    def step(self, images, true_masks):
+        """One optimisation step; returns the (device) loss tensor without forcing a host sync."""
+        net = self.net
+        images = images.to(dtype=torch.float32, memory_format=torch.channels_last)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.amp):
+            masks_pred = net(images)
+            loss = segmentation_loss(masks_pred, true_masks)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.sync.finish()
+        flat = self.sync.flat
+        if self.clip is not None and flat is not None:
+            total_norm = torch.linalg.vector_norm(flat)
+            flat.mul_(torch.clamp(self.clip / (total_norm + 1e-6), max=1.0))
+        self.optimizer.step()
+        return loss.detach()

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import UNET_CASES, golden, rel_err
+from conftest import UNET_CASES, golden, l2_err, rel_err
 from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
@@ -152,7 +152,7 @@ def test_unet_fp32_train_step_matches_reference(tag, ncls, bil, shape):
         worst = max(worst, abs(got - norms64[k]) / max(norms64[k], 1e-7))
         assert abs(got - norms64[k]) <= 2e-2 * max(norms64[k], 1e-7), (k, got, norms64[k])
     for k in [k[7:] for k in g.files if k.startswith('grad64.')]:
-        assert rel_err(npy(params[k].grad), g['grad64.' + k]) < 1e-2, k
+        assert l2_err(npy(params[k].grad), g['grad64.' + k]) < 1e-2, k
     for k in [k[6:] for k in g.files if k.startswith('after.')]:
         b = dict(net.named_buffers())[k]
         ref = g['after.' + k]
