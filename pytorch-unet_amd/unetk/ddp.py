@@ -27,6 +27,8 @@ class FlatGrads:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
+        # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum and divide after the wait
+        self.native_avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'
         self.flat = None
         self._pending = [0, 0]
         self._works = []
@@ -65,13 +67,16 @@ class FlatGrads:
     def _launch(self):
         lo, hi = self._pending
         if hi > lo:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+            self._works.append((dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True), lo, hi))
         self._pending = [hi, hi]
 
     def finish(self):
         """Call after backward(): flush the last bucket and make the compute stream wait for every all-reduce."""
         if self.world > 1:
             self._launch()
-            for w in self._works:
+            for w, lo, hi in self._works:
                 w.wait()
+                if not self.native_avg:
+                    self.flat[lo:hi].div_(self.world)
         self._works = []
