@@ -107,8 +107,12 @@ def main():
 
     roofline = None
     table = {}
-    if rank == 0:
-        # kernel timing pass: one more step with every C-ABI launch bracketed by HIP events on its stream
+    # kernel timing pass: one more step (on EVERY rank: it contains the gradient collectives) with, on rank 0,
+    # every C-ABI launch bracketed by HIP events on its stream
+    if rank != 0:
+        trainer.step(images, masks)
+        torch.cuda.synchronize()
+    else:
         with _native.KernelTimer() as kt:
             trainer.step(images, masks)
             torch.cuda.synchronize()

@@ -35,6 +35,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same LDS-DMA, hidden from the compiler.  hipcc treats the builtin as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of EVERY later ds_read it cannot prove disjoint -- which serialises a
+// double-buffered pipeline (the DMA fills buffer B while the MFMAs read buffer A).  Through inline asm the
+// instruction is invisible to that bookkeeping (cdna_hip_programming.md 5.7); completion is then OUR job: an
+// explicit `s_waitcnt vmcnt(0)` + barrier before anybody reads the destination.  M0 (the LDS base of the DMA) is
+// saved and restored inside the statement.  lds_addr must be wave-uniform.
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+  return (unsigned)(size_t)(const AS3 char*)p;
+}
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -17,7 +17,10 @@
 //         1 PWT    ConvTranspose2d k2 s2 forward: pointwise GEMM with N = 4*Co, pixel-shuffle store into
 //                  the concat buffer at a channel offset, + bias               unet_parts.py:53,62-67
 //         2 CTD    ConvTranspose2d k2 s2 dgrad: 4 stride-2 taps as outer K iterations
+#include <stdlib.h>
+
 #include "conv_common.h"
+#include "conv_config.h"
 
 namespace {
 
@@ -34,6 +37,8 @@ struct ConvParams {
   int padT, padL;
   int Co;            // PWT: channels of the up-sampled half (Cout == 4*Co)
   int tiles_x, tiles_y, n_tiles;
+  int tpb;           // spatial tiles per workgroup
+  int dbg;           // ablation flags (UNETK_CONV_DBG): 1 no DMA, 2 no MFMA loop, 4 no stores
 };
 
 template <int MODE> struct Geo;
@@ -67,46 +72,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
 
-  // ---- block -> (n_tile, image, tile origin)
-  int bid = blockIdx.x;
-  const int nt = bid % P.n_tiles;
-  bid /= P.n_tiles;
-  const int tx = bid % P.tiles_x;
-  bid /= P.tiles_x;
-  const int ty = bid % P.tiles_y;
-  const int img = bid / P.tiles_y;
-  const int y0 = ty * 8, x0 = tx * 32;
+  // ---- block -> (n_tile, a run of `tpb` consecutive spatial tiles).  Walking several tiles per workgroup lets
+  // the first chunk of tile i+1 be prefetched under the last MFMAs and the epilogue of tile i; with one tile per
+  // workgroup every tile paid an exposed HBM round trip before its first MFMA (ruinous for the K=576 layers).
+  const int nt = blockIdx.x % P.n_tiles;
+  const int grp = blockIdx.x / P.n_tiles;
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const int tile_begin = grp * P.tpb;
+  const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
 
   const int Hx = (MODE == 2) ? P.Hs : P.H, Wx = (MODE == 2) ? P.Ws : P.W;
-  const T* ximg = reinterpret_cast<const T*>(P.x) + (size_t)img * Hx * Wx * P.ldx + P.xoff;
 
-  // ---- per-thread staging descriptors (chunk-invariant)
+  // ---- per-thread staging descriptors of the tile being STAGED (chunk-invariant)
   int poff[R];    // element offset of this thread's piece inside the image, -1 = zero fill / unused
   int ldst[R];    // LDS byte address of the piece
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int id = r * 256 + tid;
     const int p = id / NP, c = id % NP;
-    int off = -1;
-    if (id < NPIECE) {
-      int yy, xx;
-      if constexpr (MODE == 0) {
-        const int hr = p / 34, hc = p - hr * 34;
-        yy = y0 + hr - 1;
-        xx = x0 + hc - 1;
-        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) off = (yy * P.W + xx) * P.ldx + c * E;
-      } else {
-        yy = y0 + (p >> 5);
-        xx = x0 + (p & 31);
-        if (yy < P.H && xx < P.W) {
-          if constexpr (MODE == 1) off = (yy * P.W + xx) * P.ldx + c * E;
-          else off = ((2 * yy + P.padT) * P.Ws + 2 * xx + P.padL) * P.ldx + c * E;
-        }
-      }
-    }
-    poff[r] = off;
     ldst[r] = p * S + ((c ^ ((p / PPR) & (NP - 1))) << 4);
   }
+  const T* ximg = nullptr;
+  auto setup_stage = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * 8, x0 = (rem % P.tiles_x) * 32;
+    ximg = reinterpret_cast<const T*>(P.x) + (size_t)img * Hx * Wx * P.ldx + P.xoff;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int id = r * 256 + tid;
+      const int p = id / NP, c = id % NP;
+      int off = -1;
+      if (id < NPIECE) {
+        int yy, xx;
+        if constexpr (MODE == 0) {
+          const int hr = p / 34, hc = p - hr * 34;
+          yy = y0 + hr - 1;
+          xx = x0 + hc - 1;
+          if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) off = (yy * P.W + xx) * P.ldx + c * E;
+        } else {
+          yy = y0 + (p >> 5);
+          xx = x0 + (p & 31);
+          if (yy < P.H && xx < P.W) {
+            if constexpr (MODE == 1) off = (yy * P.W + xx) * P.ldx + c * E;
+            else off = ((2 * yy + P.padT) * P.Ws + 2 * xx + P.padL) * P.ldx + c * E;
+          }
+        }
+      }
+      poff[r] = off;
+    }
+  };
 
   // ---- per-lane A-fragment read addresses (k-step 0; k-step s is `^ (s << 5)`)
   int aaddr[2][TAPS];
@@ -147,69 +161,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
     const int io = iter_offset(it);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      // ALWAYS issue the load (clamped address, result discarded for padding): the counted s_waitcnt below
-      // relies on every wave having exactly R prefetch loads younger than its LDS-DMA.
-      // (the zero fill for padding is applied when the piece is written to LDS, so that nothing here consumes
-      // a load result and forces an early s_waitcnt)
+      // ALWAYS issue the load (clamped address; the zero fill for padding is applied when the piece is written
+      // to LDS): the counted s_waitcnt below relies on every wave having exactly R prefetch loads younger than
+      // its LDS-DMA, and nothing here may consume a load result (that would force an early s_waitcnt).
       stage[r] = *reinterpret_cast<const uint4*>(ximg + (poff[r] >= 0 ? poff[r] : 0) + io);
     }
   };
 
-  load_stage(0);
-
-  for (int it = 0; it < niter; ++it) {
-    // [A] every wave has finished reading the previous chunk's LDS image
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (r * 256 + tid < NPIECE)
-        *reinterpret_cast<uint4*>(lds_in + ldst[r]) = poff[r] >= 0 ? stage[r] : uint4{0u, 0u, 0u, 0u};
-    // weights of this chunk: WFRAGS x 1 KiB, fragment order, straight into LDS
-    {
-      const char* wsrc = wbase + (size_t)it * (WFRAGS * 1024) + lane * 16;
-#pragma unroll
-      for (int f = 0; f < (WFRAGS + 3) / 4; ++f) {
-        const int fi = f * 4 + wid;
-        if (fi < WFRAGS) glds16(wsrc + fi * 1024, lds_w + fi * 1024);
-      }
-    }
-    const bool more = (it + 1 < niter);
-    asm volatile("" ::: "memory");   // keep the prefetch loads YOUNGER than the LDS-DMA in the vmcnt queue
-    if (more) {
-      load_stage(it + 1);
-      asm volatile("" ::: "memory");
-      // the R youngest vector-memory ops are the prefetch; everything older (the LDS-DMA) must have landed
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(R) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
-    // ---- all taps of this chunk from the one LDS image
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        uint4 a[2], b[NB];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb][t] ^ (ks << 5)));
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          b[nb] = *reinterpret_cast<const uint4*>(lds_w + ((t * KS + ks) * NB + nb) * 1024 + lane * 16);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], a[mb], b[nb]);
-      }
-    }
-  }
-
-  // ---- epilogue.  C layout of 32x32 MFMA: column = lane&31 (-> channels NB*j .. NB*j+NB-1 of this
-  // n-tile, by the weight packing), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (-> pixel column in the tile).
+  // epilogue constants.  C layout of 32x32 MFMA: column = lane&31 (-> channels NB*j .. NB*j+NB-1 of this n-tile,
+  // by the weight packing), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (-> pixel column in the tile).
   const int ch0 = nt * BN + NB * j;     // first of this lane's NB consecutive channels
-  float ssum[NB], ssq[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
-
   float bias[NB];
   int co0 = ch0, ab = 0;
   if constexpr (MODE == 1) {
@@ -219,60 +180,378 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
     for (int nb = 0; nb < NB; ++nb) bias[nb] = P.bias[co0 + nb];
   }
 
-  T* yimg;
-  if constexpr (MODE == 1) yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.Hs * P.Ws * P.ldy + P.yoff;
-  else yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+  if (tile_begin >= tile_end) return;
+  setup_stage(tile_begin);
+  load_stage(0);
 
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    for (int it = 0; it < niter; ++it) {
+      // [A] every wave has finished reading the previous chunk's LDS image (and the previous tile's `red`)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int yy = y0 + 2 * wid + mb;
+      for (int r = 0; r < R; ++r)
+        if (r * 256 + tid < NPIECE)
+          *reinterpret_cast<uint4*>(lds_in + ldst[r]) = poff[r] >= 0 ? stage[r] : uint4{0u, 0u, 0u, 0u};
+      // weights of this chunk: WFRAGS x 1 KiB, fragment order, straight into LDS
+      {
+        const char* wsrc = wbase + (size_t)it * (WFRAGS * 1024) + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (yy < P.H && xx < P.W) {
-        float v[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          float f = acc[mb][nb][i];
-          if constexpr (MODE == 1) f += bias[nb];
-          f = to_f32(from_f32<T>(f));      // statistics are taken on the value as stored
-          v[nb] = f;
-          ssum[nb] += f;
-          ssq[nb] += f * f;
+        for (int f = 0; f < (WFRAGS + 3) / 4; ++f) {
+          const int fi = f * 4 + wid;
+          if (fi < WFRAGS) glds16(wsrc + fi * 1024, lds_w + fi * 1024);
         }
-        T* dst;
-        if constexpr (MODE == 1)
-          dst = yimg + (size_t)((2 * yy + (ab >> 1) + P.padT) * P.Ws + 2 * xx + (ab & 1) + P.padL) * P.ldy + co0;
-        else
-          dst = yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0;
-        store_channels<T, NB>(dst, v);
+      }
+      asm volatile("" ::: "memory");   // keep the prefetch loads YOUNGER than the LDS-DMA in the vmcnt queue
+      const bool more_chunks = (it + 1 < niter);
+      if (more_chunks || tile + 1 < tile_end) {
+        if (more_chunks) {
+          load_stage(it + 1);
+        } else {                        // first chunk of the NEXT tile
+          setup_stage(tile + 1);
+          load_stage(0);
+        }
+        asm volatile("" ::: "memory");
+        // the R youngest vector-memory ops are the prefetch; everything older (the LDS-DMA) must have landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(R) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+
+      // ---- all taps of this chunk from the one LDS image; fragments of step s+1 are fetched into a second
+      // register set before the MFMAs of step s
+      constexpr int NSTEP = TAPS * KS;
+      uint4 fa[2][2], fb[2][NB];
+      auto load_frags = [&](int step, uint4 (&a)[2], uint4 (&b)[NB]) {
+        const int t = step / KS, ks = step % KS;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb][t] ^ (ks << 5)));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          b[nb] = *reinterpret_cast<const uint4*>(lds_w + (step * NB + nb) * 1024 + lane * 16);
+      };
+      load_frags(0, fa[0], fb[0]);
+      if constexpr (sizeof(T) == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NB, 0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) load_frags(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[st & 1][mb], fb[st & 1][nb]);
+        if constexpr (sizeof(T) == 2) {
+          if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NB, 0);   // prefetch of step st+1 ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);                       // ... then the MFMAs of step st
+        }
       }
     }
-  }
 
-  if (MODE == 0 && P.stats != nullptr) {
-    // lanes l and l+32 hold the same channels (different pixel columns)
+    // ---- epilogue of this tile (the next tile's first chunk is already in flight)
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * 8, x0 = (rem % P.tiles_x) * 32;
+    float ssum[NB], ssq[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
-      ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+    for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    T* yimg;
+    if constexpr (MODE == 1) yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.Hs * P.Ws * P.ldy + P.yoff;
+    else yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int yy = y0 + 2 * wid + mb;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (yy < P.H && xx < P.W) {
+          float v[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            float f = acc[mb][nb][i];
+            if constexpr (MODE == 1) f += bias[nb];
+            f = to_f32(from_f32<T>(f));      // statistics are taken on the value as stored
+            v[nb] = f;
+            ssum[nb] += f;
+            ssq[nb] += f * f;
+          }
+          T* dst;
+          if constexpr (MODE == 1)
+            dst = yimg + (size_t)((2 * yy + (ab >> 1) + P.padT) * P.Ws + 2 * xx + (ab & 1) + P.padL) * P.ldy + co0;
+          else
+            dst = yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0;
+          store_channels<T, NB>(dst, v);
+        }
+        acc[mb][0][i] = 0.f;
+        if constexpr (NB > 1) acc[mb][1][i] = 0.f;
+        if constexpr (NB > 2) { acc[mb][2][i] = 0.f; acc[mb][3][i] = 0.f; }
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS image no longer needed
-    float* red = reinterpret_cast<float*>(smem);                       // [4 waves][BN][2]
-    if (h == 0) {
+
+    if (MODE == 0 && P.stats != nullptr) {
+      // lanes l and l+32 hold the same channels (different pixel columns)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
-        red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
+        ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
+        ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS image no longer needed
+      float* red = reinterpret_cast<float*>(smem);                       // [4 waves][BN][2]
+      if (h == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
+          red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 2 * BN) {
+        const float v = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+        double* dst = P.stats + ((size_t)((blockIdx.x + tile) & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+        unsafeAtomicAdd(dst, (double)v);
       }
     }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const float v = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
-      double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
-      unsafeAtomicAdd(dst, (double)v);
+  }
+}
+
+// ================================================================================================================
+// conv3x3, second generation: ONE 512-thread workgroup per CU, everything double-buffered in LDS by LDS-DMA.
+//
+//   tile   16 x 32 output pixels x 64 channels; 8 waves, wave w owns tile rows 2w, 2w+1 (as above)
+//   LDS    2 x { halo tile 18 x 34 pixels x 64 B  +  9 taps x 2 k-steps x NB weight fragments of 1 KiB } = 152 KiB
+//   loop   issue the LDS-DMA of chunk k+1 (input pieces with a per-lane source address, a zero page for the padding;
+//          weights linear) -> MFMAs of chunk k -> s_waitcnt vmcnt(0) + ONE barrier.  The DMA has a whole MFMA phase
+//          (72 MFMAs per wave) to land, no VGPR staging, no ds_write, and the chunk stream runs on across the tiles a
+//          workgroup walks (the epilogue of tile i overlaps the DMA of tile i+1's first chunk).
+// The first generation exposed the weight DMA latency in every chunk (its single LDS buffer can only be refilled
+// after the barrier) and relied on a second resident workgroup to cover it.
+__device__ uint4 g_zero_page_conv[8];
+
+template <typename T, int NB, int KS, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int NP = 2 * KS, CH = NP * E, S = 32 * KS, PPR = 256 / S, TAPS = 9;
+  constexpr int HP = 34;                          // halo row pitch (pixels)
+  constexpr int TR = 2 * NW;                      // tile rows: each wave owns two
+  constexpr int NPIX = (TR + 2) * HP;
+  constexpr int IN_INSTR = (NPIX * NP + 63) / 64; // 39 one-KiB DMA pieces
+  constexpr int IN_BYTES = IN_INSTR * 1024;
+  constexpr int WFRAGS = TAPS * KS * NB;
+  constexpr int BUF = IN_BYTES + WFRAGS * 1024;
+  constexpr int BN = 32 * NB;
+  constexpr int IN_PER_WAVE = (IN_INSTR + NW - 1) / NW;
+  constexpr int W_PER_WAVE = (WFRAGS + NW - 1) / NW;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+
+  const int nt = blockIdx.x % P.n_tiles;
+  const int grp = blockIdx.x / P.n_tiles;
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const int tile_begin = grp * P.tpb;
+  const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
+  if (tile_begin >= tile_end) return;
+
+  const int nchunks = P.Cin / CH;
+  const char* wbase = reinterpret_cast<const char*>(P.wpk) + (size_t)nt * nchunks * (WFRAGS * 1024);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_conv);
+
+  // per-lane A-fragment read addresses (k-step 0 of the chunk; k-step 1 is ^32)
+  int aaddr[2][TAPS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int p = (2 * wid + mb + t / 3) * HP + j + (t % 3);
+      aaddr[mb][t] = p * S + ((h ^ ((p / PPR) & (NP - 1))) << 4);
+    }
+
+  // DMA descriptors of the tile being staged: byte offset of this lane's piece (chunk 0) or -1 -> zero page
+  long dma_off[IN_PER_WAVE];
+  const char* ximg = nullptr;
+  auto setup_stage = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    ximg = reinterpret_cast<const char*>(reinterpret_cast<const T*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+#pragma unroll
+    for (int f = 0; f < IN_PER_WAVE; ++f) {
+      const int fi = f * NW + wid;
+      const int id = fi * 64 + lane;           // LDS slot: pixel p, physical piece s
+      const int p = id / NP, sl = id % NP;
+      const int c = sl ^ ((p / PPR) & (NP - 1));   // logical piece stored in that slot
+      const int hr = p / HP, hc = p - hr * HP;
+      const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+      long off = -1;
+      if (p < NPIX && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W)
+        off = ((long)(yy * P.W + xx) * P.ldx + c * E) * (long)sizeof(T);
+      dma_off[f] = off;
+    }
+  };
+  // one 1-KiB DMA piece: q < IN_PER_WAVE -> input piece q, else weight fragment q - IN_PER_WAVE
+  constexpr int NDMA = IN_PER_WAVE + W_PER_WAVE;
+  auto issue_piece = [&](int q, int chunk, unsigned buf) {
+    if (q < IN_PER_WAVE) {
+      const int fi = q * NW + wid;
+      if (fi < IN_INSTR) {
+        const char* src = dma_off[q] >= 0 ? ximg + dma_off[q] + (long)chunk * CH * sizeof(T) : zero;
+        glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+      }
+    } else {
+      const int fi = (q - IN_PER_WAVE) * NW + wid;
+      if (fi < WFRAGS) glds16_hidden(wbase + (size_t)chunk * (WFRAGS * 1024) + lane * 16 + fi * 1024,
+                                    __builtin_amdgcn_readfirstlane(buf + IN_BYTES + fi * 1024));
+    }
+  };
+  auto issue_dma = [&](int chunk, unsigned buf) {
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, chunk, buf);
+  };
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  const int ch0 = nt * BN + NB * j;
+
+  setup_stage(tile_begin);
+  const unsigned lds0 = lds_address(smem);
+  issue_dma(0, lds0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    for (int kc = 0; kc < nchunks; ++kc) {
+      char* lds_in = smem + cur * BUF;
+      char* lds_w = lds_in + IN_BYTES;
+      // DMA of the next chunk (of this tile or the first of the next tile) into the other buffer, ONE piece per
+      // k-step between the MFMAs: an LDS-DMA instruction holds the issuing wave for 60-185 cycles
+      // (MI355X_MICROARCH "LDS-DMA piece issue cost"); issued in a burst at the top of the iteration all eight waves
+      // stall together and the matrix pipe drains, spread out the partner wave on the SIMD keeps it fed.
+      int next_chunk = -1;
+      if (P.dbg & 1) {
+      } else if (kc + 1 < nchunks) {
+        next_chunk = kc + 1;
+      } else if (tile + 1 < tile_end) {
+        setup_stage(tile + 1);
+        next_chunk = 0;
+      }
+      const unsigned nbuf = lds0 + (cur ^ 1) * BUF;
+      constexpr int NSTEP = TAPS * KS;
+      static_assert(NDMA <= NSTEP, "one DMA piece per k-step");
+      uint4 fa[2][2], fb[2][NB];
+      auto load_frags = [&](int step, uint4 (&a)[2], uint4 (&b)[NB]) {
+        const int t = step / KS, ks = step % KS;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb][t] ^ (ks << 5)));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          b[nb] = *reinterpret_cast<const uint4*>(lds_w + (step * NB + nb) * 1024 + lane * 16);
+      };
+      if (!(P.dbg & 2)) {
+      load_frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) load_frags(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
+        if (st < NDMA && next_chunk >= 0) issue_piece(st, next_chunk, nbuf);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[st & 1][mb], fb[st & 1][nb]);
+      }
+      } else if (next_chunk >= 0) {
+        issue_dma(next_chunk, nbuf);
+      }
+      // next chunk landed (this wave's DMAs) and every wave is done reading the current buffer
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      cur ^= 1;
+    }
+
+    // ---- epilogue of this tile
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    float ssum[NB], ssq[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int yy = y0 + 2 * wid + mb;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (yy < P.H && xx < P.W) {
+          float v[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
+            v[nb] = f;
+            ssum[nb] += f;
+            ssq[nb] += f * f;
+          }
+          if (!(P.dbg & 4)) store_channels<T, NB>(yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0, v);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
+      }
+    }
+    if (P.stats != nullptr) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
+        ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+      }
+      // the buffer that was just consumed (cur^1 after the flip) is free until the next iteration's DMA issue,
+      // which comes after the second barrier below
+      float* red = reinterpret_cast<float*>(smem + (cur ^ 1) * BUF);     // [NW waves][BN][2]
+      if (h == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
+          red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 2 * BN) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += red[w8 * 2 * BN + tid];
+        double* dst = P.stats + ((size_t)((blockIdx.x + tile) & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+        unsafeAtomicAdd(dst, (double)v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
+}
+
+template <typename T, int NB, int KS, int NW> int launch_db(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * ((size_t)(((2 * NW + 2) * 34 * 2 * KS + 63) / 64) * 1024 + 9 * KS * NB * 1024);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_db_kernel<T, NB, KS, NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNETK_ERR_LAUNCH;
+    attr_done = true;
+  }
+  ConvParams Q = P;
+  Q.tiles_y = host_cdiv(P.H, 2 * NW);
+  const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
+  const int nchunks = P.Cin / (2 * KS * ElemTraits<T>::E);
+  Q.n_tiles = P.Cout / (32 * NB);
+  // one workgroup per CU is resident: keep >= ~16 rounds of workgroups over the 256 CUs (small tail), >= 8 chunks each
+  int tpb = (int)((ntiles * Q.n_tiles) / 4096);
+  const int tmin = (8 * 2 / KS + nchunks - 1) / nchunks;
+  if (tpb < tmin) tpb = tmin;
+  if (tpb > 16) tpb = 16;
+  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  Q.tpb = tpb;
+  Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
+  const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
 }
 
 template <typename T, int NB, int MODE> size_t lds_bytes() {
@@ -291,14 +570,35 @@ template <typename T, int NB, int MODE> int launch(const ConvParams& P, hipStrea
       return UNETK_ERR_LAUNCH;
     attr_done = true;
   }
-  const long nblk = (long)P.N * P.tiles_y * P.tiles_x * P.n_tiles;
+  // tiles per workgroup: enough K-iterations per workgroup (>= ~12 chunks) to amortise the pipeline fill, as long
+  // as the grid still holds >= ~8 workgroups per CU
+  ConvParams Q = P;
+  const long ntiles = (long)P.N * P.tiles_y * P.tiles_x;
+  using G = Geo<MODE>;
+  const int niter = (P.Cin / (2 * G::KS * ElemTraits<T>::E)) * G::OUTER;
+  int tpb = (12 + niter - 1) / niter;
+  while (tpb > 1 && ((ntiles + tpb - 1) / tpb) * P.n_tiles < 2048) --tpb;
+  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  Q.tpb = tpb;
+  const long nblk = ((ntiles + tpb - 1) / tpb) * P.n_tiles;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NB, MODE>), dim3((unsigned)nblk), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NB, MODE>), dim3((unsigned)nblk), dim3(256), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
 
 template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) {
+  if constexpr (MODE == 0) {
+    constexpr int gen = 2;   // conv3x3 always runs the double-buffered LDS-DMA kernel; the register-staged kernel
+                             // above still serves the transposed-conv modes
+    const Conv3Config cfg = conv3_config(P.Cout);
+    if (gen == 2 || cfg.NB == 4) {
+      if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+      if (cfg.NB == 4) return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8>(P, s) : launch_db<float, 4, 1, 8>(P, s);
+      // 64-channel-wide outputs (measured: two 4-wave workgroups per CU with 32-byte chunks were 10 % slower)
+      return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
+    }
+  }
   if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);
   if (dtype == UNETK_F32) return launch<float, 2, MODE>(P, s);
   return UNETK_ERR_DTYPE;

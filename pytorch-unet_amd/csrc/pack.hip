@@ -3,26 +3,26 @@
 // consecutive K-channels  kc*CH + ks*2E + h*E + e  of GEMM-N channel  nt*BN + NB*j + nb  (the NB channels of
 // one lane are adjacent so the epilogue stores NB-wide vectors).
 #include "common.h"
+#include "conv_config.h"
 
 namespace {
 
-struct PackGeo { int N, K, taps, KS, outer; };
+struct PackGeo { int N, K, taps, KS, outer, NB; };
 
 bool pack_geo(int kind, int c_out, int c_in, PackGeo* g) {
   switch (kind) {
-    case 0: *g = {c_out, c_in, 9, 2, 1}; return true;
-    case 1: *g = {c_in, c_out, 9, 2, 1}; return true;
-    case 2: *g = {4 * c_out, c_in, 1, 4, 1}; return true;
-    case 3: *g = {c_in, c_out, 1, 4, 4}; return true;
+    case 0: { const Conv3Config c = conv3_config(c_out); *g = {c_out, c_in, 9, c.KS, 1, c.NB}; return true; }
+    case 1: { const Conv3Config c = conv3_config(c_in); *g = {c_in, c_out, 9, c.KS, 1, c.NB}; return true; }
+    case 2: *g = {4 * c_out, c_in, 1, 4, 1, 2}; return true;
+    case 3: *g = {c_in, c_out, 1, 4, 4, 2}; return true;
   }
   return false;
 }
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int kind, int c_out, int c_in, int N,
-                            int K, int taps, int KS, int outer, long npieces) {
+                            int K, int taps, int KS, int outer, int NB, long npieces) {
   constexpr int E = ElemTraits<T>::E;
-  constexpr int NB = 2;
   const int CH = 2 * KS * E;
   const int nchunks = K / CH;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npieces; idx += (long)gridDim.x * blockDim.x) {
@@ -80,10 +80,10 @@ int unetk_pack_weight(int kind, const float* src, void* dst, int c_out, int c_in
   const int grid = (int)((npieces + 255) / 256 > 4096 ? 4096 : (npieces + 255) / 256);
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, kind, c_out,
-                       c_in, g.N, g.K, g.taps, g.KS, g.outer, npieces);
+                       c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, npieces);
   else
     hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, kind,
-                       c_out, c_in, g.N, g.K, g.taps, g.KS, g.outer, npieces);
+                       c_out, c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, npieces);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
