@@ -102,6 +102,45 @@ __global__ void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const flo
   }
 }
 
+// The same pass when the pieces of one pixel divide the 256-thread block (every channel count the U-Net has):
+// a thread keeps ONE channel piece for the whole launch, so its per-channel coefficients live in registers and
+// the loop body is pure streaming (two pixels per trip for more bytes in flight).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_fixed_kernel(const T* __restrict__ y, int ldy,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, T* __restrict__ out,
+                                                                  int ldo, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const int lanes = 256 / ppp;
+  const int c0 = (threadIdx.x % ppp) * E;
+  const int plane = threadIdx.x / ppp;
+  float sc[E], sh[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; }
+  const long step = (long)gridDim.x * lanes;
+  long pix = (long)blockIdx.x * lanes + plane;
+  for (; pix + step < npix; pix += 2 * step) {
+    float v0[E], v1[E];
+    Vec<T>::load(y + pix * ldy + c0, v0);
+    Vec<T>::load(y + (pix + step) * ldy + c0, v1);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      v0[i] = fmaxf(fmaf(v0[i], sc[i], sh[i]), 0.f);
+      v1[i] = fmaxf(fmaf(v1[i], sc[i], sh[i]), 0.f);
+    }
+    Vec<T>::store(out + pix * ldo + c0, v0);
+    Vec<T>::store(out + (pix + step) * ldo + c0, v1);
+  }
+  if (pix < npix) {
+    float v0[E];
+    Vec<T>::load(y + pix * ldy + c0, v0);
+#pragma unroll
+    for (int i = 0; i < E; ++i) v0[i] = fmaxf(fmaf(v0[i], sc[i], sh[i]), 0.f);
+    Vec<T>::store(out + pix * ldo + c0, v0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ BN + ReLU backward
 // pass 1: per-channel  S1 = sum dz,  S2 = sum dz*xhat   with dz = dout * [bn(y) > 0], xhat = (y-mean)*invstd
 template <typename T>
@@ -198,6 +237,54 @@ __global__ void bn_relu_bwd_apply_kernel(const T* __restrict__ dout, int lddo, c
       o[i] = coef[c] * dz - coef[C + c] - coef[2 * C + c] * (v[i] - mean[c]);
     }
     Vec<T>::store(dy + pix * lddy + c0, o);
+  }
+}
+
+// fixed-piece variant (see bn_relu_apply_fixed_kernel): 5 coefficient rows in registers, two pixels per trip
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_fixed_kernel(
+    const T* __restrict__ dout, int lddo, const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ coef,
+    T* __restrict__ dy, int lddy, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const int lanes = 256 / ppp;
+  const int c0 = (threadIdx.x % ppp) * E;
+  const int plane = threadIdx.x / ppp;
+  float sc[E], sh[E], mu[E], ka[E], kb[E], kc[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i];
+    ka[i] = coef[c0 + i]; kb[i] = coef[C + c0 + i]; kc[i] = coef[2 * C + c0 + i];
+  }
+  const long step = (long)gridDim.x * lanes;
+  long pix = (long)blockIdx.x * lanes + plane;
+  for (; pix + step < npix; pix += 2 * step) {
+    float g0[E], v0[E], g1[E], v1[E];
+    Vec<T>::load(dout + pix * lddo + c0, g0);
+    Vec<T>::load(y + pix * ldy + c0, v0);
+    Vec<T>::load(dout + (pix + step) * lddo + c0, g1);
+    Vec<T>::load(y + (pix + step) * ldy + c0, v1);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float d0 = fmaf(v0[i], sc[i], sh[i]) > 0.f ? g0[i] : 0.f;
+      const float d1 = fmaf(v1[i], sc[i], sh[i]) > 0.f ? g1[i] : 0.f;
+      g0[i] = ka[i] * d0 - kb[i] - kc[i] * (v0[i] - mu[i]);
+      g1[i] = ka[i] * d1 - kb[i] - kc[i] * (v1[i] - mu[i]);
+    }
+    Vec<T>::store(dy + pix * lddy + c0, g0);
+    Vec<T>::store(dy + (pix + step) * lddy + c0, g1);
+  }
+  if (pix < npix) {
+    float g0[E], v0[E];
+    Vec<T>::load(dout + pix * lddo + c0, g0);
+    Vec<T>::load(y + pix * ldy + c0, v0);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const float d0 = fmaf(v0[i], sc[i], sh[i]) > 0.f ? g0[i] : 0.f;
+      g0[i] = ka[i] * d0 - kb[i] - kc[i] * (v0[i] - mu[i]);
+    }
+    Vec<T>::store(dy + pix * lddy + c0, g0);
   }
 }
 
@@ -454,8 +541,8 @@ int check_act(const void* p, int ld, int c, int dtype) {
 
 }  // namespace
 
-#define DISPATCH_T(dtype, CALL)                  \
-  if ((dtype) == UNETK_BF16) { using T = bf16; CALL; } else { using T = float; CALL; }
+#define DISPATCH_T(dtype, ...)                   \
+  if ((dtype) == UNETK_BF16) { using T = bf16; __VA_ARGS__; } else { using T = float; __VA_ARGS__; }
 
 extern "C" {
 
@@ -485,8 +572,15 @@ int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float*
   if (int e = check_act(y, ldy, c, dtype)) return e;
   if (int e = check_act(out, ldo, c, dtype)) return e;
   if (!scale || !shift || npix <= 0) return UNETK_ERR_ARG;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ew_grid(npix * (c / Vec<T>::E))), dim3(256), 0,
-                                       (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (long)npix, c));
+  DISPATCH_T(dtype, {
+    const int ppp = c / Vec<T>::E;
+    if (ppp <= 256 && 256 % ppp == 0)
+      hipLaunchKernelGGL(bn_relu_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (long)npix, c);
+    else
+      hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)y, ldy, scale, shift, (T*)out, ldo, (long)npix, c);
+  });
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -528,9 +622,16 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
   if (int e = check_act(y, ldy, c, dtype)) return e;
   if (int e = check_act(dy, lddy, c, dtype)) return e;
   if (!scale || !shift || !mean || !coef || npix <= 0) return UNETK_ERR_ARG;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * (c / Vec<T>::E))), dim3(256), 0,
-                                       (hipStream_t)stream, (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean,
-                                       coef, (T*)dy, lddy, (long)npix, c));
+  DISPATCH_T(dtype, {
+    const int ppp = c / Vec<T>::E;
+    if (ppp <= 256 && 256 % ppp == 0)
+      hipLaunchKernelGGL(bn_relu_bwd_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy,
+                         lddy, (long)npix, c);
+    else
+      hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
+                         (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy, lddy, (long)npix, c);
+  });
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

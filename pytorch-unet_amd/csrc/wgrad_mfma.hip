@@ -200,6 +200,189 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
     }
 }
 
+// ================================================================================================================
+// conv3x3 wgrad, second generation.  The first-generation loop above reads 10 fragments (1 KiB each) from LDS per
+// 9 MFMAs -- 1.1 KiB per MFMA, more than the 128 B/clk LDS port can deliver at the matrix pipe's rate.  Here GEMM-K
+// (16 pixels per MFMA) runs DOWN a pixel column instead of along a row: the A fragment of (column c, kernel row kh)
+// is then the SAME registers for kw = 0,1,2 (it pairs with the dy fragments of columns c, c-1, c-2), so a column
+// step needs 3 A + 1 B fragments for 9 MFMAs (0.44 KiB per MFMA).
+//
+//   tile     16 rows x 16 columns of output pixels; LDS per buffer: x halo 18 x 19(pitch) pixels + dy 16 x 17(pitch)
+//            pixels, 128 B (64 channels) each = 77 KiB; the odd pitches + a 64-byte XOR by bit 1 of the row make the
+//            transposed column reads (ds_read_b64_tr_b16, 4 rows x 32 B per 16 lanes) bank-conflict free
+//   block    8 waves, ONE workgroup per CU, two LDS buffers filled by LDS-DMA hidden from the compiler (common.h):
+//            waves 0-3 take dy columns 0-7, waves 4-7 columns 8-15; inside a group 2 x 2 waves of 32 x 32 channels,
+//            all nine taps in 144 accumulator registers for the whole tile range (split-K over the grid)
+//   loop     per tile 10 column steps: fragments of step c+1 are fetched while the MFMAs of step c run, one DMA piece
+//            of the NEXT tile is issued per step, one barrier per tile
+// Partial sums: slab[2*split + group][tap][ci][co], summed in fixed order by wgrad_reduce_kernel.
+struct Wgrad3Params {
+  const bf16* a;      // layer input x
+  const bf16* b;      // dy
+  float* slab;
+  int N, H, W, Ca, Cb, lda, ldb;
+  int tiles_x, tiles_y, ntiles, nsplit, row_tiles, col_tiles;
+  int dbg;            // UNETK_WGRAD_DBG ablation (perf work only): 1 or 16 = every DMA source is the zero page
+};
+
+constexpr int W3_AP = 19, W3_BP = 17;
+constexpr int W3_A_PIECES = (18 * W3_AP + 7) / 8;   // 43
+constexpr int W3_B_PIECES = (16 * W3_BP) / 8;       // 34
+constexpr int W3_PIECES = W3_A_PIECES + W3_B_PIECES;
+constexpr int W3_BUF = W3_PIECES * 1024;
+constexpr int W3_STEPS = 10;
+
+__device__ __forceinline__ int swz3(int row) { return ((row >> 1) & 1) << 2; }
+
+__global__ __launch_bounds__(512) void wgrad3_bf16_kernel(Wgrad3Params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wi = (wid >> 1) & 1, wj = wid & 1;
+
+  // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH: round-robin dispatch).  All channel-tile pairs of one split read
+  // the SAME pixel tiles, so consecutive (split, pair) indices are laid out XCD-major: an XCD's 32 CUs then hold one
+  // split's pairs and fetch every pixel tile into their L2 once instead of once per XCD.
+  const int npairs = P.row_tiles * P.col_tiles;
+  int lin = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int pair = lin % npairs, split = lin / npairs;
+  const int r0 = (pair / P.col_tiles) * 64, c0 = (pair % P.col_tiles) * 64;
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  // ---- per-lane transposed-read addresses inside a buffer (column 8*grp; later columns are immediates)
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+  const int sub = (pp & 1) * 8;
+  int addrA[3][2], addrB[2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int k = 8 * (g >> 1) + 4 * rd + q4;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int row = kh + k;
+      const int piece = wi * 4 + 2 * (g & 1) + (pp >> 1);
+      addrA[kh][rd] = (row * W3_AP + grp * 8) * 128 + ((piece ^ swz3(row)) << 4) + sub;
+    }
+    const int pieceb = wj * 4 + 2 * (g & 1) + (pp >> 1);
+    addrB[rd] = W3_A_PIECES * 1024 + (k * W3_BP + grp * 8) * 128 + ((pieceb ^ swz3(k)) << 4) + sub;
+  }
+
+  // ---- DMA descriptors, tile invariant: piece fi = q*8 + wid covers 8 pixel slots x 8 sixteen-byte slots
+  //      packed: bits 0-7 row+1 rel. to the tile, 8-15 col+1, 16-19 channel piece, 24 valid
+  //      (slots 77-79 of the 8 x 10 issue grid repeat piece 76: same bytes to the same place, no branch)
+  int desc[W3_STEPS];
+  const int lp = lane >> 3, ls = lane & 7;
+#pragma unroll
+  for (int q = 0; q < W3_STEPS; ++q) {
+    const int fi = min(q * 8 + wid, W3_PIECES - 1);
+    int d = 0;
+    if (fi < W3_A_PIECES) {
+      const int p = fi * 8 + lp;
+      const int hr = p / W3_AP, hc = p - hr * W3_AP;
+      if (hc < 18 && hr < 18) d = hr | (hc << 8) | ((ls ^ swz3(hr)) << 16) | (1 << 24);
+    } else {
+      const int p = (fi - W3_A_PIECES) * 8 + lp;
+      const int hr = p / W3_BP, hc = p - hr * W3_BP;
+      if (hc < 16) d = (hr + 1) | ((hc + 1) << 8) | ((ls ^ swz3(hr)) << 16) | (1 << 24);
+    }
+    desc[q] = d;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const unsigned lds0 = lds_address(smem);
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+
+  // scalars of the tile being staged
+  const char* sa = nullptr;
+  const char* sb = nullptr;
+  int sy0 = 0, sx0 = 0;
+  auto stage_tile = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    sy0 = (rem / P.tiles_x) * 16;
+    sx0 = (rem % P.tiles_x) * 16;
+    sa = reinterpret_cast<const char*>(P.a + (size_t)img * P.H * P.W * P.lda + r0);
+    sb = reinterpret_cast<const char*>(P.b + (size_t)img * P.H * P.W * P.ldb + c0);
+  };
+  // Branch-free on purpose: a branch inside the MFMA loop ends the basic block, and hipcc then waits for EVERY
+  // outstanding ds_read (the prefetched fragments of the next step included) before the step's first MFMA.
+  auto issue_piece = [&](int q, unsigned buf, bool live) {
+    const int fi = min(q * 8 + wid, W3_PIECES - 1);
+    const bool is_a = fi < W3_A_PIECES;
+    const int d = desc[q];
+    const int yy = sy0 + (d & 255) - 1, xx = sx0 + ((d >> 8) & 255) - 1;
+    const int ld = is_a ? P.lda : P.ldb;
+    const char* base = is_a ? sa : sb;
+    const bool ok = live & ((d >> 24) != 0) & ((unsigned)yy < (unsigned)P.H) & ((unsigned)xx < (unsigned)P.W) &
+                    !(P.dbg & 16);
+    const unsigned off = ((unsigned)(yy * P.W + xx) * (unsigned)ld + ((d >> 16) & 15) * 8u) * 2u;
+    const char* src = ok ? base + off : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+
+  if (t_begin < t_end) {
+    stage_tile(t_begin);
+#pragma unroll
+    for (int q = 0; q < W3_STEPS; ++q) issue_piece(q, lds0, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const char* buf = smem + cur * W3_BUF;
+    const unsigned nbuf = lds0 + (cur ^ 1) * W3_BUF;
+    const bool next = tile + 1 < t_end && !(P.dbg & 1);   // last tile: the pieces still issue, from the zero page
+    stage_tile(next ? tile + 1 : tile);
+
+    bf16x8 fa[2][3], fb[4];
+    auto load_step = [&](int cc) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+        fa[cc & 1][kh] = tr_read8(buf + addrA[kh][0] + cc * 128, buf + addrA[kh][1] + cc * 128);
+      if (cc < 8) fb[cc & 3] = tr_read8(buf + addrB[0] + cc * 128, buf + addrB[1] + cc * 128);
+    };
+    load_step(0);
+#pragma unroll
+    for (int cc = 0; cc < W3_STEPS; ++cc) {
+      if (cc + 1 < W3_STEPS) load_step(cc + 1);
+      issue_piece(cc, nbuf, next);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int bl = cc - kw;
+        if (bl >= 0 && bl < 8) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cc & 1][kh], fb[bl & 3], acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    cur ^= 1;
+  }
+  const int j = lane & 31, h = lane >> 5;
+  float* out = P.slab + (size_t)(split * 2 + grp) * 9 * P.Ca * P.Cb;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      out[((size_t)t * P.Ca + row) * P.Cb + c0 + wj * 32 + j] = acc[t][i];
+    }
+}
+
+int pick_nsplit3(int ntiles, int npairs) {
+  int ns = 256 / npairs;
+  if (ns < 1) ns = 1;
+  if (ns > ntiles) ns = ntiles;
+  return ns;
+}
+
 // out[row*s_row + col*s_col + tap] = sum_s slab[s][tap][row][col]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int taps,
                                     int rows, int cols, long s_row, long s_col, int accumulate) {
@@ -371,8 +554,13 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
   const int ntiles = n * host_cdiv(h, 8) * host_cdiv(w, 32);
   const int npairs = (c_in / 64) * (c_out / 64);
   const int taps = kind == 0 ? 9 : 4;
-  // bf16 uses 64x64 channel tiles, fp32 32x32 (4x the pairs, hence fewer splits): size for the larger (bf16) case
-  return (int64_t)pick_nsplit(ntiles, npairs) * taps * c_in * c_out * 4;
+  // fp32 uses 32x32 channel tiles (4x the pairs, hence fewer splits than the 64x64 bf16 kernels): size for bf16
+  int64_t slabs = pick_nsplit(ntiles, npairs);
+  if (kind == 0) {   // bf16 conv3x3: 16x16-pixel tiles, two partial slabs (one per wave group) per split
+    const int64_t s3 = 2 * (int64_t)pick_nsplit3(n * host_cdiv(h, 16) * host_cdiv(w, 16), npairs);
+    if (s3 > slabs) slabs = s3;
+  }
+  return slabs * taps * c_in * c_out * 4;
 }
 
 int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
@@ -409,26 +597,28 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
-  WgradParams P{};
+  if ((int64_t)h * w * (ldx > lddy ? ldx : lddy) * 2 >= (int64_t)1 << 32) return UNETK_ERR_SHAPE;   // 32-bit DMA offsets
+  Wgrad3Params P{};
   P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
   P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
-  P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
+  P.tiles_x = host_cdiv(w, 16); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
-  P.nsplit = pick_nsplit(P.ntiles, P.row_tiles * P.col_tiles);
-  const size_t lds = 10 * 36 * 128 + 256 * 128;
+  P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
+  P.dbg = getenv("UNETK_WGRAD_DBG") ? atoi(getenv("UNETK_WGRAD_DBG")) : 0;
+  const size_t lds = 2 * W3_BUF;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<0>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_bf16_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return UNETK_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_bf16_kernel<0>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
+  hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                      (hipStream_t)stream, P);
   UNETK_CHECK_LAUNCH();
   const long total = 9L * c_in * c_out;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, dw, P.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
+                     (const float*)workspace, dw, 2 * P.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

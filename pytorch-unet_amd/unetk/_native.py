@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libunetk.so')
+LIB_PATH = os.environ.get('UNETK_LIB') or os.path.join(os.path.dirname(_HERE), 'libunetk.so')   # UNETK_LIB: perf A/B builds
 
 BF16, F32 = 0, 1
 STAT_REPLICAS = 32
