@@ -53,6 +53,21 @@ def cpu_baseline(seconds_budget=25.0):
                       f'torch {torch.__version__} CPU, {threads} threads'}
 
 
+def pmc_traffic():
+    """HBM bytes per conv3x3 fprop/dgrad launch from the committed rocprofv3 --pmc passes of THIS command
+    (profiles/*_conv_traffic.json, made by scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md 'HBM'); counters cannot be read from inside the timed process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_conv_traffic.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -125,9 +140,11 @@ def main():
                 fl += table[name][2]
         if ms > 0:
             achieved = fl / (ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<bf16,NB=2,CONV3> (conv3x3 fprop + dgrad)',
+            roofline = {'bound': 'mfma',
+                        'kernel': 'conv3x3_db_kernel<bf16> (conv3x3 fprop + dgrad launches of one step; '
+                                  '128-channel NB=4 and 64-channel NB=2 instantiations)',
                         'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': 2500.0,
-                        'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': None}
+                        'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': pmc_traffic()}
         total_ms = sum(v[1] for v in table.values())
         sys.stderr.write('kernel-time table of one step (HIP events, serialised by the event brackets):\n')
         for name, (n, m, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):

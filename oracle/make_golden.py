@@ -245,10 +245,14 @@ for tag, (ncls, bil, shape) in {
     logits64 = net64(img.double())
     seg_loss(net64, logits64, mask).backward()
     norms64 = []
+    grads32 = {k: p.grad.detach().double() for k, p in net.named_parameters()}
     for k, p in net64.named_parameters():
         norms64.append(float(p.grad.norm()))
         if k in KEEP_FULL:
             arrs['grad64.' + k] = p.grad.detach().numpy().astype(np.float32)
+            # how far the reference's OWN fp32 gradient is from the exact one (L2-relative): the yardstick for the
+            # gradients that sit behind ReLU masks of near-zero pre-activations
+            arrs['grad_gap32.' + k] = np.array(float((grads32[k] - p.grad).norm() / p.grad.norm()))
     arrs['grad_norms64'] = np.array(norms64)
     arrs['logits_train64'] = npy(logits64)
     # the reference's own bf16 training-mode forward (fresh net, batch statistics): the yardstick for what

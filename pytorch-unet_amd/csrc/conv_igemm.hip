@@ -19,6 +19,8 @@
 //         2 CTD    ConvTranspose2d k2 s2 dgrad: 4 stride-2 taps as outer K iterations
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 #include "conv_config.h"
 
@@ -38,6 +40,7 @@ struct ConvParams {
   int Co;            // PWT: channels of the up-sampled half (Cout == 4*Co)
   int tiles_x, tiles_y, n_tiles;
   int tpb;           // spatial tiles per workgroup
+  int nblk;          // workgroups that have work (first-generation kernel: the grid is padded to a multiple of 8)
   int dbg;           // ablation flags (UNETK_CONV_DBG): 1 no DMA, 2 no MFMA loop, 4 no stores
 };
 
@@ -75,8 +78,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
   // ---- block -> (n_tile, a run of `tpb` consecutive spatial tiles).  Walking several tiles per workgroup lets
   // the first chunk of tile i+1 be prefetched under the last MFMAs and the epilogue of tile i; with one tile per
   // workgroup every tile paid an exposed HBM round trip before its first MFMA (ruinous for the K=576 layers).
-  const int nt = blockIdx.x % P.n_tiles;
-  const int grp = blockIdx.x / P.n_tiles;
+  // The n-tiles of one spatial tile read the same input pixels.  Workgroup b runs on XCD b % 8, so consecutive
+  // (tile group, n-tile) indices are laid out XCD-major: the n-tiles of a tile group then share one XCD's L2
+  // (with b % n_tiles every XCD streamed the whole input: 7.5x the algorithmic bytes at the L2's fabric side).
+  // The grid is padded to a multiple of 8; surplus workgroups leave before the first barrier.
+  const int lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (lin >= P.nblk) return;
+  const int nt = lin % P.n_tiles;
+  const int grp = lin / P.n_tiles;
   const int tiles_per_img = P.tiles_x * P.tiles_y;
   const int tile_begin = grp * P.tpb;
   const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
@@ -420,6 +429,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   issue_dma(0, lds0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   int cur = 0;
+  // BN statistics of all tiles of this workgroup: per tile in fp32 (as the values are produced), across tiles in
+  // fp32 for bf16 tensors and in fp64 for fp32 tensors (their 1e-4 parity bar needs E[x^2] - mean^2 to keep its bits)
+  using StatAcc = typename std::conditional<sizeof(T) == 4, double, float>::type;
+  StatAcc tsum[NB], tsq[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) tsum[nb] = tsq[nb] = 0;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int kc = 0; kc < nchunks; ++kc) {
@@ -468,20 +483,24 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
       cur ^= 1;
     }
 
-    // ---- epilogue of this tile
+    // ---- epilogue of this tile.  64-bit address arithmetic only per row block (wave-uniform); an element adds a
+    // 32-bit lane offset and a compile-time multiple of the pixel pitch.
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+    const int lane_off = 4 * h * P.ldy + ch0;
+    const int xl = x0 + 4 * h;
     float ssum[NB], ssq[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
-    T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       const int yy = y0 + 2 * wid + mb;
+      T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (yy < P.H && xx < P.W) {
+        const int ri = (i & 3) + 8 * (i >> 2);
+        if (yy < P.H && xl + ri < P.W) {
           float v[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
@@ -490,37 +509,38 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
             ssum[nb] += f;
             ssq[nb] += f * f;
           }
-          if (!(P.dbg & 4)) store_channels<T, NB>(yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0, v);
+          if (!(P.dbg & 4)) store_channels<T, NB>(rowp + ri * P.ldy + lane_off, v);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
       }
     }
-    if (P.stats != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { tsum[nb] += (StatAcc)ssum[nb]; tsq[nb] += (StatAcc)ssq[nb]; }
+  }
+
+  // ---- one LDS reduction and one set of fp64 atomics per workgroup
+  if (P.stats != nullptr) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      tsum[nb] += __shfl_xor(tsum[nb], 32, 64);
+      tsq[nb] += __shfl_xor(tsq[nb], 32, 64);
+    }
+    StatAcc* red = reinterpret_cast<StatAcc*>(smem);   // [NW waves][BN][2]; every DMA landed, every read retired
+    if (h == 0) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
-        ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+        red[(wid * BN + NB * j + nb) * 2 + 0] = tsum[nb];
+        red[(wid * BN + NB * j + nb) * 2 + 1] = tsq[nb];
       }
-      // the buffer that was just consumed (cur^1 after the flip) is free until the next iteration's DMA issue,
-      // which comes after the second barrier below
-      float* red = reinterpret_cast<float*>(smem + (cur ^ 1) * BUF);     // [NW waves][BN][2]
-      if (h == 0) {
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 2 * BN) {
+      StatAcc v = 0;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
-          red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (tid < 2 * BN) {
-        float v = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) v += red[w8 * 2 * BN + tid];
-        double* dst = P.stats + ((size_t)((blockIdx.x + tile) & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
-        unsafeAtomicAdd(dst, (double)v);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      for (int w8 = 0; w8 < NW; ++w8) v += red[w8 * 2 * BN + tid];
+      double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+      unsafeAtomicAdd(dst, (double)v);
     }
   }
 }
@@ -554,6 +574,241 @@ template <typename T, int NB, int KS, int NW> int launch_db(const ConvParams& P,
   return UNETK_OK;
 }
 
+// ================================================================================================================
+// ConvTranspose2d k2 s2 forward (MODE 1) and dgrad (MODE 2), second generation: the same double-buffered hidden
+// LDS-DMA pipeline as conv3x3_db_kernel, for the pointwise GEMMs.
+//
+//   tile   512 CONSECUTIVE pixels of the flattened low-res grid (no 2-D tile, no ragged-edge waste) x 128 channels;
+//          8 waves, wave w owns pixels 64w .. 64w+63 (two 32-pixel MFMA row blocks) x 4 column blocks
+//   LDS    2 x { 512 pixels x 128 B (64 bf16 / 32 fp32 channels)  +  4 k-steps x 4 weight fragments } = 160 KiB
+//   loop   chunk = (tap,) 64 channels: 4 k-steps x 8 MFMAs per wave; the 10 DMA pieces per wave of the next chunk go
+//          out 3,3,3,1 between the k-steps; one barrier per chunk
+//   MODE 1 epilogue: + bias, pixel-shuffle store (tap = channel / Co) into the concat buffer at a channel offset
+//   MODE 2 operand:  per tap the stride-2 gather of the up-sampled gradient (per-lane DMA source addresses)
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int NB = 4, KS = 4, NW = 8;
+  constexpr int NP = 2 * KS, CH = NP * E, S = 32 * KS;
+  constexpr int TP = 64 * NW;                     // pixels per tile
+  constexpr int IN_INSTR = TP * S / 1024;         // 64
+  constexpr int IN_BYTES = IN_INSTR * 1024;
+  constexpr int WFRAGS = KS * NB;                 // 16
+  constexpr int BUF = IN_BYTES + WFRAGS * 1024;
+  constexpr int BN = 32 * NB;
+  constexpr int IN_PER_WAVE = IN_INSTR / NW;      // 8
+  constexpr int W_PER_WAVE = WFRAGS / NW;         // 2
+  constexpr int NDMA = IN_PER_WAVE + W_PER_WAVE;  // 10
+  constexpr int PPS = (NDMA + KS - 1) / KS;       // DMA pieces per k-step
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+
+  const int lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-major, see conv_igemm_kernel
+  if (lin >= P.nblk) return;
+  const int nt = lin % P.n_tiles;
+  const int grp = lin / P.n_tiles;
+  const long npix = (long)P.N * P.H * P.W;
+  const int ntiles = (int)((npix + TP - 1) / TP);
+  const int tile_begin = grp * P.tpb;
+  const int tile_end = min(tile_begin + P.tpb, ntiles);
+  if (tile_begin >= tile_end) return;
+
+  const int nchunks = P.Cin / CH;
+  const int niter = nchunks * (MODE == 2 ? 4 : 1);
+  const char* wbase = reinterpret_cast<const char*>(P.wpk) + (size_t)nt * niter * (WFRAGS * 1024);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_conv);
+  const char* xbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(P.x) + P.xoff);
+  const int HW = P.H * P.W;
+
+  int aaddr[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int p = (2 * wid + mb) * 32 + j;
+    aaddr[mb] = p * S + ((h ^ ((p >> 1) & (NP - 1))) << 4);
+  }
+
+  // byte offset (chunk 0 / tap 0) of this lane's 16 bytes of every input piece, -1 -> zero page
+  long dma_off[IN_PER_WAVE];
+  auto setup_stage = [&](int tile) {
+#pragma unroll
+    for (int f = 0; f < IN_PER_WAVE; ++f) {
+      const int fi = f * NW + wid;
+      const int id = fi * 64 + lane;
+      const int p = id / NP, sl = id % NP;
+      const int c = sl ^ ((p >> 1) & (NP - 1));
+      const long g = (long)tile * TP + p;
+      long off = -1;
+      if (g < npix) {
+        if constexpr (MODE == 1) {
+          off = (g * P.ldx + c * E) * (long)sizeof(T);
+        } else {
+          const int img = (int)(g / HW), r = (int)(g - (long)img * HW);
+          const int yy = r / P.W, xx = r - yy * P.W;
+          off = ((((long)img * P.Hs + 2 * yy + P.padT) * P.Ws + 2 * xx + P.padL) * P.ldx + c * E) * (long)sizeof(T);
+        }
+      }
+      dma_off[f] = off;
+    }
+  };
+  auto iter_bytes = [&](int it) -> long {
+    if constexpr (MODE == 2) {
+      const int tap = it / nchunks, kc = it - tap * nchunks;
+      return ((long)((tap >> 1) * P.Ws + (tap & 1)) * P.ldx + kc * CH) * (long)sizeof(T);
+    } else {
+      return (long)it * CH * (long)sizeof(T);
+    }
+  };
+  // branch-free (a branch inside the MFMA loop ends the basic block and costs a full lgkmcnt(0) wait)
+  auto issue_piece = [&](int q, int it, long ib, unsigned buf, bool live) {
+    if (q < IN_PER_WAVE) {
+      const int fi = q * NW + wid;
+      const char* src = (live && dma_off[q] >= 0) ? xbase + dma_off[q] + ib : zero;
+      glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    } else {
+      const int fi = (q - IN_PER_WAVE) * NW + wid;
+      const char* src = live ? wbase + (size_t)it * (WFRAGS * 1024) + lane * 16 + fi * 1024 : zero;
+      glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + IN_BYTES + fi * 1024));
+    }
+  };
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  const int ch0 = nt * BN + NB * j;
+  float bias[NB];
+  int co0 = ch0, ab = 0;
+  if constexpr (MODE == 1) {
+    ab = ch0 / P.Co;
+    co0 = ch0 - ab * P.Co;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bias[nb] = P.bias[co0 + nb];
+  }
+
+  setup_stage(tile_begin);
+  const unsigned lds0 = lds_address(smem);
+#pragma unroll
+  for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0, lds0, true);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    for (int it = 0; it < niter; ++it) {
+      const char* lds_in = smem + cur * BUF;
+      const char* lds_w = lds_in + IN_BYTES;
+      const bool last_it = it + 1 == niter;
+      const bool live = (!last_it || tile + 1 < tile_end) && !(P.dbg & 1);
+      if (last_it && live) setup_stage(tile + 1);
+      const int nit = last_it ? 0 : it + 1;
+      const long nib = iter_bytes(nit);
+      const unsigned nbuf = lds0 + (cur ^ 1) * BUF;
+
+      uint4 fa[2][2], fb[2][NB];
+      auto load_frags = [&](int ks, uint4 (&a)[2], uint4 (&b)[NB]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb] ^ (ks << 5)));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          b[nb] = *reinterpret_cast<const uint4*>(lds_w + (ks * NB + nb) * 1024 + lane * 16);
+      };
+      load_frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+        for (int q = ks * PPS; q < (ks + 1) * PPS && q < NDMA; ++q) issue_piece(q, nit, nib, nbuf, live);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[ks & 1][mb], fb[ks & 1][nb]);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      cur ^= 1;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const long gb = (long)tile * TP + (2 * wid + mb) * 32;       // wave-uniform
+      // 64-bit address arithmetic once per row block (wave-uniform); per element a 32-bit element offset
+      if constexpr (MODE == 1) {
+        const int img0 = (int)(gb / HW), r0 = (int)(gb - (long)img0 * HW);
+        const int yb = r0 / P.W, xb = r0 - yb * P.W;
+        T* dst0 = reinterpret_cast<T*>(P.y) + P.yoff + co0 +
+                  (((size_t)img0 * P.Hs + 2 * yb + (ab >> 1) + P.padT) * P.Ws + 2 * xb + (ab & 1) + P.padL) * P.ldy;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (gb + row < npix) {
+            int xx = xb + row, dy2 = 0;          // dy2 = 2 * (rows of the up-sampled image below dst0's)
+            while (xx >= P.W) { xx -= P.W; dy2 += 2; }
+            // rows past the image's last one continue in the next image: H low-res rows = Hs up-sampled rows apart
+            int yy = yb + (dy2 >> 1);
+            while (yy >= P.H) { yy -= P.H; dy2 += P.Hs - 2 * P.H; }
+            float v[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) v[nb] = acc[mb][nb][i] + bias[nb];
+            if (!(P.dbg & 4)) store_channels<T, NB>(dst0 + (dy2 * P.Ws + 2 * (xx - xb)) * P.ldy, v);
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
+        }
+      } else {
+        T* dst0 = reinterpret_cast<T*>(P.y) + P.yoff + (size_t)gb * P.ldy + ch0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (gb + row < npix) {
+            float v[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) v[nb] = acc[mb][nb][i];
+            store_channels<T, NB>(dst0 + row * P.ldy, v);
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int MODE> int launch_pw(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * (64 * 1024 + 16 * 1024);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_db_kernel<T, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return UNETK_ERR_LAUNCH;
+    attr_done = true;
+  }
+  ConvParams Q = P;
+  Q.n_tiles = P.Cout / 128;
+  const long npix = (long)P.N * P.H * P.W;
+  const long ntiles = (npix + 511) / 512;
+  const int niter = (P.Cin / (8 * ElemTraits<T>::E)) * (MODE == 2 ? 4 : 1);
+  // one workgroup per CU: ~8 rounds of workgroups over the chip, at least ~8 chunks per workgroup
+  int tpb = (int)((ntiles * Q.n_tiles) / 2048);
+  const int tmin = (8 + niter - 1) / niter;
+  if (tpb < tmin) tpb = tmin;
+  if (tpb > 16) tpb = 16;
+  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  Q.tpb = tpb;
+  Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
+  const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
+  if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
+  Q.nblk = (int)nblk;
+  hipLaunchKernelGGL((pw_db_kernel<T, MODE>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(512), lds, s, Q);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
 template <typename T, int NB, int MODE> size_t lds_bytes() {
   using G = Geo<MODE>;
   size_t main_bytes = (size_t)G::NPIX * G::KS * 32 + (size_t)G::TAPS * G::KS * NB * 1024;
@@ -581,8 +836,9 @@ template <typename T, int NB, int MODE> int launch(const ConvParams& P, hipStrea
   if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
   Q.tpb = tpb;
   const long nblk = ((ntiles + tpb - 1) / tpb) * P.n_tiles;
-  if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NB, MODE>), dim3((unsigned)nblk), dim3(256), lds, s, Q);
+  if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
+  Q.nblk = (int)nblk;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NB, MODE>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(256), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -597,6 +853,13 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       if (cfg.NB == 4) return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8>(P, s) : launch_db<float, 4, 1, 8>(P, s);
       // 64-channel-wide outputs (measured: two 4-wave workgroups per CU with 32-byte chunks were 10 % slower)
       return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
+    }
+  }
+  if constexpr (MODE != 0) {
+    if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)
+      if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
+      if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
+      return UNETK_ERR_DTYPE;
     }
   }
   if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);

@@ -13,8 +13,8 @@ bool pack_geo(int kind, int c_out, int c_in, PackGeo* g) {
   switch (kind) {
     case 0: { const Conv3Config c = conv3_config(c_out); *g = {c_out, c_in, 9, c.KS, 1, c.NB}; return true; }
     case 1: { const Conv3Config c = conv3_config(c_in); *g = {c_in, c_out, 9, c.KS, 1, c.NB}; return true; }
-    case 2: *g = {4 * c_out, c_in, 1, 4, 1, 2}; return true;
-    case 3: *g = {c_in, c_out, 1, 4, 4, 2}; return true;
+    case 2: *g = {4 * c_out, c_in, 1, 4, 1, pw_nb(4 * c_out)}; return true;
+    case 3: *g = {c_in, c_out, 1, 4, 4, pw_nb(c_in)}; return true;
   }
   return false;
 }

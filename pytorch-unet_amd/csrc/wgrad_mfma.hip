@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
   const int wi = wid >> 1, wj = wid & 1;
 
   const int npairs = P.row_tiles * P.col_tiles;
-  const int pair = blockIdx.x % npairs, split = blockIdx.x / npairs;
+  int lin = blockIdx.x;     // XCD-major order: the channel-tile pairs of one split share an XCD's L2 (see wgrad3)
+  if ((gridDim.x & 7) == 0) lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int pair = lin % npairs, split = lin / npairs;
   const int rt = pair / P.col_tiles, ct = pair % P.col_tiles;
   const int r0 = rt * 64, c0 = ct * 64;
 

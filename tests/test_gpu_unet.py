@@ -151,8 +151,13 @@ def test_unet_fp32_train_step_matches_reference(tag, ncls, bil, shape):
         got = float(params[k].grad.double().norm())
         worst = max(worst, abs(got - norms64[k]) / max(norms64[k], 1e-7))
         assert abs(got - norms64[k]) <= 2e-2 * max(norms64[k], 1e-7), (k, got, norms64[k])
+    # full gradients against the reference's fp64 run.  Gradients behind ReLU masks of near-zero pre-activations
+    # (the 40-sample BatchNorm at the bottleneck above all) move by ~1 % when one mask flips: the reference's OWN
+    # fp32 gradient is grad_gap32 away from the exact one (1.2 % for down4's BN bias in the 21-class case), so the
+    # bar is 1e-2 or twice that gap, whichever is larger.
     for k in [k[7:] for k in g.files if k.startswith('grad64.')]:
-        assert l2_err(npy(params[k].grad), g['grad64.' + k]) < 1e-2, k
+        tol = max(1e-2, 2.0 * float(g['grad_gap32.' + k]))
+        assert l2_err(npy(params[k].grad), g['grad64.' + k]) < tol, (k, tol)
     for k in [k[6:] for k in g.files if k.startswith('after.')]:
         b = dict(net.named_buffers())[k]
         ref = g['after.' + k]
