@@ -471,16 +471,31 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int lds_, T* __r
 // zero the F.pad border (unet_parts.py:62-63) of the up-sampled channel slice that convT does not write
 template <typename T>
 __global__ void zero_border_kernel(T* buf, int ld, int N, int Hs, int Ws, int C, int padT, int padL, int hu, int wu) {
+  // enumerates ONLY the border pixels: padT full rows on top, (Ws - wu) pixels of each of the hu middle rows,
+  // the remaining full rows at the bottom
   constexpr int E = Vec<T>::E;
   const int ppp = C / E;
-  const long total = (long)N * Hs * Ws * ppp;
+  const int side = Ws - wu;                       // border pixels per middle row
+  const int n_top = padT * Ws, n_mid = hu * side;
+  const int per_img = Hs * Ws - hu * wu;
+  const long total = (long)N * per_img * ppp;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     long r = idx;
     const int c0 = (int)(r % ppp) * E; r /= ppp;
-    const int X = (int)(r % Ws); r /= Ws;
-    const int Y = (int)(r % Hs);
-    const long n = r / Hs;
-    if (Y >= padT && Y < padT + hu && X >= padL && X < padL + wu) continue;
+    int b = (int)(r % per_img);
+    const long n = r / per_img;
+    int X, Y;
+    if (b < n_top) {
+      Y = b / Ws; X = b - Y * Ws;
+    } else if (b < n_top + n_mid) {
+      b -= n_top;
+      const int row = b / side, k = b - row * side;
+      Y = padT + row; X = k < padL ? k : k + wu;
+    } else {
+      b -= n_top + n_mid;
+      const int row = b / Ws;
+      Y = padT + hu + row; X = b - row * Ws;
+    }
     *reinterpret_cast<uint4*>(buf + ((n * Hs + Y) * Ws + X) * ld + c0) = uint4{0u, 0u, 0u, 0u};
   }
 }
@@ -504,14 +519,27 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
     float s[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) s[i] = 0.f;
-    const long npix = (long)N * wh * ww;
-    for (long q = (long)blockIdx.x * lanes + plane; q < npix; q += (long)gridDim.x * lanes) {
-      const int xx = (int)(q % ww);
-      const long r = q / ww;
-      const int yy = (int)(r % wh);
-      const long n = r / wh;
+    // window pixels in 32-bit arithmetic (the entry point checks N*wh*ww < 2^31), four independent loads in flight
+    const int npix = N * wh * ww;
+    const int step = gridDim.x * lanes;
+    auto addr = [&](int q) {
+      const int xx = q % ww, r = q / ww;
+      const int yy = r % wh, n = r / wh;
+      return x + (((long)n * Hs + wy + yy) * Ws + wx + xx) * ld + piece * E;
+    };
+    int q = blockIdx.x * lanes + plane;
+    for (; q + 3 * step < npix; q += 4 * step) {
+      float v0[E], v1[E], v2[E], v3[E];
+      Vec<T>::load(addr(q), v0);
+      Vec<T>::load(addr(q + step), v1);
+      Vec<T>::load(addr(q + 2 * step), v2);
+      Vec<T>::load(addr(q + 3 * step), v3);
+#pragma unroll
+      for (int i = 0; i < E; ++i) s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+    }
+    for (; q < npix; q += step) {
       float v[E];
-      Vec<T>::load(x + ((n * Hs + wy + yy) * Ws + wx + xx) * ld + piece * E, v);
+      Vec<T>::load(addr(q), v);
 #pragma unroll
       for (int i = 0; i < E; ++i) s[i] += v[i];
     }
@@ -705,7 +733,8 @@ int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int p
   if (int e = check_act(buf, ld, c, dtype)) return e;
   if (n <= 0 || pad_t < 0 || pad_l < 0 || pad_t + h_up > hs || pad_l + w_up > ws) return UNETK_ERR_SHAPE;
   if (h_up == hs && w_up == ws) return UNETK_OK;   // nothing to pad
-  const long items = (long)n * hs * ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  if ((long)hs * ws >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+  const long items = (long)n * ((long)hs * ws - (long)h_up * w_up) * (c / (dtype == UNETK_BF16 ? 8 : 4));
   DISPATCH_T(dtype, hipLaunchKernelGGL(zero_border_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
                                        (T*)buf, ld, n, hs, ws, c, pad_t, pad_l, h_up, w_up));
   UNETK_CHECK_LAUNCH();
@@ -716,7 +745,7 @@ int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int w
                       double* scratch, float* out, int dtype, void* stream) {
   if (int e = check_act(x, ld, c, dtype)) return e;
   if (!scratch || !out || n <= 0 || win_y < 0 || win_x < 0 || win_h <= 0 || win_w <= 0 || win_y + win_h > hs ||
-      win_x + win_w > ws)
+      win_x + win_w > ws || (long)n * win_h * win_w >= 0x7fffffffL - 4L * kMaxGrid * 256)
     return UNETK_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(scratch, 0, (size_t)c * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
@@ -726,7 +755,7 @@ int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int w
   if (256 % pg) return UNETK_ERR_SHAPE;
   const int lanes = 256 / pg;
   long gx = ((long)n * win_h * win_w + lanes - 1) / lanes;
-  if (gx > 512) gx = 512;
+  if (gx > kMaxGrid) gx = kMaxGrid;
   dim3 grid((unsigned)gx, (unsigned)((ppp + 255) / 256));
   DISPATCH_T(dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, n, hs, ws, c,
                                        win_y, win_x, win_h, win_w, scratch));
