@@ -50,6 +50,49 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
   __syncthreads();
   const int ppp = Cin / E;
   const int sub = threadIdx.x % G, pl = threadIdx.x / G, lanes = 256 / G;
+  if (ppp == G) {
+    // one piece per lane (Cin <= 64 pieces, the U-Net's 64-channel head): weights in registers, four pixels'
+    // loads in flight per trip
+    float wr[CT][E];
+#pragma unroll
+    for (int k = 0; k < CT; ++k)
+#pragma unroll
+      for (int i = 0; i < E; ++i) wr[k][i] = wl[k * Cin + sub * E + i];
+    const long step = (long)gridDim.x * lanes;
+    for (long pix0 = (long)blockIdx.x * lanes + pl; pix0 < npix; pix0 += 4 * step) {
+      float v[4][E], acc[4][CT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long pix = pix0 + u * step;
+        load_piece<T>(x + (pix < npix ? pix : pix0) * ldx + sub * E, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < CT; ++k) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < E; ++i) a = fmaf(v[u][i], wr[k][i], a);
+          acc[u][k] = a;
+        }
+      for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < CT; ++k) acc[u][k] += __shfl_xor(acc[u][k], o, 64);
+      if (sub == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long pix = pix0 + u * step;
+          if (pix < npix)
+#pragma unroll
+            for (int k = 0; k < CT; ++k)
+              if (cbase + k < ncls) out[pix * ldo + cbase + k] = from_f32<T>(acc[u][k] + bias[cbase + k]);
+        }
+      }
+    }
+    return;
+  }
   for (long pix0 = (long)blockIdx.x * lanes; pix0 < npix; pix0 += (long)gridDim.x * lanes) {
     const long pix = pix0 + pl;
     float acc[CT];
@@ -121,7 +164,25 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < E; ++i) acc[k][i] = 0.f;
   }
-  for (long pix = (long)blockIdx.x * lanes + pl; pix < npix; pix += (long)gridDim.x * lanes) {
+  const long step = (long)gridDim.x * lanes;
+  long pix = (long)blockIdx.x * lanes + pl;
+  for (; pix + step < npix; pix += 2 * step) {      // two pixels' loads in flight
+    float v0[E], v1[E], g0[CT], g1[CT];
+    load_piece<T>(x + pix * ldx + piece * E, v0);
+    load_piece<T>(x + (pix + step) * ldx + piece * E, v1);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      g0[k] = (cbase + k < ncls) ? to_f32(dl[pix * lddl + cbase + k]) : 0.f;
+      g1[k] = (cbase + k < ncls) ? to_f32(dl[(pix + step) * lddl + cbase + k]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+      accb[k] += g0[k] + g1[k];
+#pragma unroll
+      for (int i = 0; i < E; ++i) acc[k][i] = fmaf(g1[k], v1[i], fmaf(g0[k], v0[i], acc[k][i]));
+    }
+  }
+  if (pix < npix) {
     float v[E];
     load_piece<T>(x + pix * ldx + piece * E, v);
 #pragma unroll
@@ -145,18 +206,27 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const T* __restrict_
   }
 }
 
-__global__ void conv1x1_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, float* dw, float* db, int Cin,
-                                            int ncls) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncls * (Cin + 1)) return;
+__global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, float* dw,
+                                                                   float* db, int Cin, int ncls) {
+  // one workgroup per output element; fixed summation order (thread-strided partials, then a tree)
+  __shared__ float part[256];
+  const int idx = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * ncls * (Cin + 1) + idx];
-  const int k = idx / (Cin + 1), c = idx - k * (Cin + 1);
-  if (c < Cin) dw[k * Cin + c] = s;
-  else if (db) db[k] = s;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += slab[(size_t)b * ncls * (Cin + 1) + idx];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int k = idx / (Cin + 1), c = idx - k * (Cin + 1);
+    if (c < Cin) dw[k * Cin + c] = part[0];
+    else if (db) db[k] = part[0];
+  }
 }
 
-constexpr int kWgradBlocks = 512;
+constexpr int kWgradBlocks = 2048;
 
 int check_head(const void* x, int ldx, int cin, int ncls, int dtype) {
   if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
@@ -238,7 +308,7 @@ int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float*
                        (const float*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes);
   UNETK_CHECK_LAUNCH();
   const int total = n_classes * (c_in + 1);
-  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)gx, dw, db, c_in, n_classes);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
