@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
 //            all nine taps in 144 accumulator registers for the whole tile range (split-K over the grid)
 //   loop     per tile 10 column steps: fragments of step c+1 are fetched while the MFMAs of step c run, one DMA piece
 //            of the NEXT tile is issued per step, one barrier per tile
-// Partial sums: slab[2*split + group][tap][ci][co], summed in fixed order by wgrad_reduce_kernel.
+// Partial sums: the two groups are added through LDS, then slab[split][tap][ci][co]; the splits are summed in
+// fixed order by wgrad_reduce_kernel.
 struct Wgrad3Params {
   const bf16* a;      // layer input x
   const bf16* b;      // dy
@@ -367,15 +368,28 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(Wgrad3Params P) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     cur ^= 1;
   }
-  const int j = lane & 31, h = lane >> 5;
-  float* out = P.slab + (size_t)(split * 2 + grp) * 9 * P.Ca * P.Cb;
+  // ---- the two column groups are summed through LDS (free now: every DMA landed, every read retired at the last
+  // barrier); group 0 writes the workgroup's partial sums
+  float* xch = reinterpret_cast<float*>(smem);           // [9][16][256] floats = 144 KiB
+  const int t256 = tid & 255;
+  if (grp == 1) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = r0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      out[((size_t)t * P.Ca + row) * P.Cb + c0 + wj * 32 + j] = acc[t][i];
-    }
+      for (int i = 0; i < 16; ++i) xch[(t * 16 + i) * 256 + t256] = acc[t][i];
+  }
+  __syncthreads();
+  if (grp == 0) {
+    const int j = lane & 31, h = lane >> 5;
+    float* out = P.slab + (size_t)split * 9 * P.Ca * P.Cb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = r0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        out[((size_t)t * P.Ca + row) * P.Cb + c0 + wj * 32 + j] = acc[t][i] + xch[(t * 16 + i) * 256 + t256];
+      }
+  }
 }
 
 int pick_nsplit3(int ntiles, int npairs) {
@@ -385,9 +399,38 @@ int pick_nsplit3(int ntiles, int npairs) {
   return ns;
 }
 
-// out[row*s_row + col*s_col + tap] = sum_s slab[s][tap][row][col]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int taps,
-                                    int rows, int cols, long s_row, long s_col, int accumulate) {
+// out[col][row][tap] = sum_s slab[s][tap][row][col]   (out = PyTorch's [Co][Ci][3][3] resp. [Ci][Co][2][2]: s_col =
+// rows*taps, s_row = taps).  One workgroup = 32 cols x 8 rows x all taps, transposed through LDS: the slab is read in
+// 128-byte runs (32 cols), the parameter gradient written in runs of 8*taps floats.  Fixed summation order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                           int nsplit, int taps, int rows, int cols, long s_row,
+                                                           long s_col, int accumulate) {
+  __shared__ float tile[9 * 8 * 33];
+  const int col_tiles = cols / 32;
+  const int c0 = (blockIdx.x % col_tiles) * 32, r0 = (blockIdx.x / col_tiles) * 8;
+  const long total = (long)taps * rows * cols;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  for (int t = 0; t < taps; ++t) {
+    const long idx = ((long)t * rows + r0 + rl) * cols + c0 + cl;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + idx];
+    tile[(t * 8 + rl) * 33 + cl] = s;
+  }
+  __syncthreads();
+  const int per_col = 8 * taps;
+  for (int e = threadIdx.x; e < 32 * per_col; e += 256) {
+    const int c = e / per_col, rem = e - c * per_col;
+    const int r = rem / taps, t = rem - r * taps;
+    float* o = out + (long)(c0 + c) * s_col + (long)(r0 + r) * s_row + t;
+    const float v = tile[(t * 8 + r) * 33 + c];
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+// The same sum, one output element per thread (coalesced slab reads, scattered writes): many splits over a small
+// weight tensor (the 64..128-channel layers), where the transposing kernel above would have too few workgroups.
+__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int taps,
+                                         int rows, int cols, long s_row, long s_col, int accumulate) {
   const long total = (long)taps * rows * cols;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -398,6 +441,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int tap = (int)(rem / rows);
     float* o = out + row * s_row + col * s_col + tap;
     *o = accumulate ? *o + s : s;
+  }
+}
+
+void launch_wgrad_reduce(const float* slab, float* out, int nsplit, int taps, int rows, int cols, int accumulate,
+                         hipStream_t stream) {
+  const long s_row = taps, s_col = (long)rows * taps;
+  if (nsplit <= 16) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((cols / 32) * (rows / 8))), dim3(256), 0, stream, slab, out,
+                       nsplit, taps, rows, cols, s_row, s_col, accumulate);
+  } else {
+    const long total = (long)taps * rows * cols;
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, slab, out,
+                       nsplit, taps, rows, cols, s_row, s_col, accumulate);
   }
 }
 
@@ -558,8 +614,8 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
   const int taps = kind == 0 ? 9 : 4;
   // fp32 uses 32x32 channel tiles (4x the pairs, hence fewer splits than the 64x64 bf16 kernels): size for bf16
   int64_t slabs = pick_nsplit(ntiles, npairs);
-  if (kind == 0) {   // bf16 conv3x3: 16x16-pixel tiles, two partial slabs (one per wave group) per split
-    const int64_t s3 = 2 * (int64_t)pick_nsplit3(n * host_cdiv(h, 16) * host_cdiv(w, 16), npairs);
+  if (kind == 0) {   // bf16 conv3x3: 16x16-pixel tiles
+    const int64_t s3 = pick_nsplit3(n * host_cdiv(h, 16) * host_cdiv(w, 16), npairs);
     if (s3 > slabs) slabs = s3;
   }
   return slabs * taps * c_in * c_out * 4;
@@ -594,8 +650,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
                        (hipStream_t)stream, Q);
     UNETK_CHECK_LAUNCH();
     const long totalq = 9L * c_in * c_out;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((totalq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, dw, Q.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
+    launch_wgrad_reduce((const float*)workspace, dw, Q.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
@@ -619,8 +674,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
                      (hipStream_t)stream, P);
   UNETK_CHECK_LAUNCH();
   const long total = 9L * c_in * c_out;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, dw, 2 * P.nsplit, 9, c_in, c_out, 9L, (long)c_in * 9, accumulate);
+  launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -657,8 +711,7 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
                        (hipStream_t)stream, Q);
     UNETK_CHECK_LAUNCH();
     const long totalq = 4L * c_in * c_out;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((totalq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)workspace, dw, Q.nsplit, 4, c_out, c_in, 4L, (long)c_out * 4, accumulate);
+    launch_wgrad_reduce((const float*)workspace, dw, Q.nsplit, 4, c_out, c_in, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
@@ -682,8 +735,7 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
   UNETK_CHECK_LAUNCH();
   // rows = co, cols = ci ; parameter layout [Ci][Co][2][2]
   const long total = 4L * c_in * c_out;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, dw, P.nsplit, 4, c_out, c_in, 4L, (long)c_out * 4, accumulate);
+  launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 4, c_out, c_in, accumulate, (hipStream_t)stream);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
