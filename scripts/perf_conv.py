@@ -8,6 +8,8 @@ N = int(os.environ.get('N', 16))
 layers = [(640, 959, 64, 64), (640, 959, 128, 64), (320, 479, 64, 128), (320, 479, 128, 128), (320, 479, 256, 128),
           (160, 239, 128, 256), (160, 239, 256, 256), (160, 239, 512, 256), (80, 119, 256, 512), (80, 119, 512, 512),
           (80, 119, 1024, 512), (40, 59, 512, 1024), (40, 59, 1024, 1024)]
+if os.environ.get('ONLY'):
+    layers = [layers[int(i)] for i in os.environ['ONLY'].split(',')]
 dt = torch.bfloat16 if os.environ.get('DT', 'bf16') == 'bf16' else torch.float32
 for (h, w, cin, cout) in layers:
     x = (torch.rand((N, h, w, cin), device='cuda') - 0.5).to(dt)
@@ -16,7 +18,7 @@ for (h, w, cin, cout) in layers:
     stats = ops.new_stats(cout, 'cuda') if os.environ.get('STATS', '1') == '1' else None
     y = ops.conv3x3_fprop(x, wpk, cout, stats=stats)
     torch.cuda.synchronize()
-    reps = 5
+    reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
         ops.conv3x3_fprop(x, wpk, cout, out=y, stats=stats)
