@@ -9,7 +9,12 @@ namespace {
 template <typename T> struct Vec {
   static constexpr int E = ElemTraits<T>::E;
   static __device__ __forceinline__ void load(const T* p, float (&v)[E]) {
+#ifndef EW_NO_NT_LOAD
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const uint4 raw = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#else
     const uint4 raw = *reinterpret_cast<const uint4*>(p);
+#endif
     if constexpr (sizeof(T) == 2) {
       const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
@@ -25,20 +30,37 @@ template <typename T> struct Vec {
       bf16x8 b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
-      *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, b);
+      put(p, __builtin_bit_cast(uint4, b));
     } else {
       f32x4 f = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f);
+      put(p, __builtin_bit_cast(uint4, f));
     }
+  }
+  static __device__ __forceinline__ void put(T* p, uint4 raw) {
+#ifndef EW_NO_NT_STORE
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, raw), reinterpret_cast<u32x4*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = raw;
+#endif
   }
 };
 
-constexpr int kMaxGrid = 256 * 8;   // memory-bound grids: ~8 blocks per CU, grid-stride the rest (Guideline 11)
+#ifndef EW_GRID_MUL
+#define EW_GRID_MUL 8
+#endif
+constexpr int kMaxGrid = 256 * EW_GRID_MUL;   // memory-bound grids: ~8 blocks per CU, grid-stride the rest (Guideline 11)
 
-inline int ew_grid(long work_items, int per_block = 256) {
+inline int ew_grid(long work_items, int per_block = 256, int max_grid = kMaxGrid) {
   long g = (work_items + per_block - 1) / per_block;
-  return (int)(g > kMaxGrid ? kMaxGrid : (g < 1 ? 1 : g));
+  return (int)(g > max_grid ? max_grid : (g < 1 ? 1 : g));
 }
+#ifndef EW_APPLY_MUL
+#define EW_APPLY_MUL 2
+#endif
+#ifndef EW_BWD_MUL
+#define EW_BWD_MUL 4
+#endif
 
 // ------------------------------------------------------------------------------------------ BN finalize
 // unet_parts.py:17,20 (aten::batch_norm, training): biased variance for normalisation, unbiased for the
@@ -603,7 +625,7 @@ int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float*
   DISPATCH_T(dtype, {
     const int ppp = c / Vec<T>::E;
     if (ppp <= 256 && 256 % ppp == 0)
-      hipLaunchKernelGGL(bn_relu_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp)), dim3(256), 0,
+      hipLaunchKernelGGL(bn_relu_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp, 256 * EW_APPLY_MUL)), dim3(256), 0,
                          (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (long)npix, c);
     else
       hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
@@ -653,7 +675,7 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
   DISPATCH_T(dtype, {
     const int ppp = c / Vec<T>::E;
     if (ppp <= 256 && 256 % ppp == 0)
-      hipLaunchKernelGGL(bn_relu_bwd_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp)), dim3(256), 0,
+      hipLaunchKernelGGL(bn_relu_bwd_apply_fixed_kernel<T>, dim3(ew_grid(npix, 256 / ppp, 256 * EW_BWD_MUL)), dim3(256), 0,
                          (hipStream_t)stream, (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy,
                          lddy, (long)npix, c);
     else
