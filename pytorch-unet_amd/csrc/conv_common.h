@@ -21,23 +21,25 @@ template <> struct Mma<float> {
   }
 };
 
-// NB adjacent output channels of one lane -> one vector store
+// NB adjacent output channels of one lane -> one vector store.  Nontemporal: a conv output is streamed once to HBM
+// and next read by another kernel; keeping it out of the way leaves L2 to the weight stream and the halo re-reads.
 template <typename T, int NB> __device__ __forceinline__ void store_channels(T* p, const float (&v)[NB]) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (NB == 2) {
       bf16x2 o = {(bf16)v[0], (bf16)v[1]};
-      *reinterpret_cast<bf16x2*>(p) = o;
+      __builtin_nontemporal_store(__builtin_bit_cast(unsigned, o), reinterpret_cast<unsigned*>(p));
     } else {
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *reinterpret_cast<bf16x4*>(p) = o;
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(p));
     }
   } else {
     if constexpr (NB == 2) {
       f32x2 o = {v[0], v[1]};
-      *reinterpret_cast<f32x2*>(p) = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(p));
     } else {
       f32x4 o = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(p) = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p));
     }
   }
 }

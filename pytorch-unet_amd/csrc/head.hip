@@ -26,10 +26,10 @@ template <typename T> __device__ __forceinline__ void store_piece(T* p, const fl
     bf16x8 b;
 #pragma unroll
     for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
-    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, b);
+    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, b), reinterpret_cast<f32x4*>(p));
   } else {
     f32x4 f = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, f);
+    __builtin_nontemporal_store(f, reinterpret_cast<f32x4*>(p));
   }
 }
 
