@@ -855,8 +855,8 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
       if (cfg.NB == 4) return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8>(P, s) : launch_db<float, 4, 1, 8>(P, s);
       // 64-channel-wide outputs (measured: two 4-wave workgroups per CU with 32-byte chunks were 10 % slower)
-      if (cfg.KS == 1)    // perf A/B (UNETK_CONV_KS64=1): two independent 4-wave workgroups per CU -- measured 4 % slower
-        return dtype == UNETK_BF16 ? launch_db<bf16, 2, 1, 4>(P, s) : launch_db<float, 2, 1, 4>(P, s);
+      if (cfg.KS == 1)    // perf A/B (UNETK_CONV_KS64=1): 32 x 32-pixel tiles, 4 row blocks per wave (0.75 KiB LDS / MFMA)
+        return dtype == UNETK_BF16 ? launch_db<bf16, 2, 1, 8, 4>(P, s) : launch_db<float, 2, 1, 8, 4>(P, s);
       return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
     }
   }
