@@ -1,0 +1,158 @@
+"""Full-size checks (BASELINE.json configs[1] layer shapes: 959x640 and its pyramid) through the C ABI.
+
+The NumPy oracle would need minutes at these sizes, so the checks are size-independent properties instead:
+
+* integer-valued operands: x, dy in {-1,0,1} and sparse weights in {-1,0,1} make every product and every partial
+  sum an exactly representable integer (|sum| <= 256 for the bf16 outputs, < 2^24 for the fp32 weight gradients), so
+  the MFMA kernels must agree BIT-EXACTLY with an independent evaluation of the same contraction (im2col + fp32
+  GEMM by torch on the same GPU), whatever the tiling, split-K order or rounding point;
+* the fused BatchNorm statistics must equal the exact integer sums of the stored output;
+* pooling: max-pool forward equals torch's, and its backward routes every gradient to exactly one input.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(shape, seed, density=1.0):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randint(-1, 2, shape, generator=g).float()
+    if density < 1.0:
+        v = v * (torch.rand(shape, generator=g) < density).float()
+    return v
+
+
+def _im2col(x_nhwc):
+    """[1,H,W,C] fp32 -> [H*W, C*9] with (c, kh, kw) column order (F.unfold's)."""
+    x = x_nhwc.permute(0, 3, 1, 2).float()
+    return F.unfold(x, kernel_size=3, padding=1)[0].t()
+
+
+CONV_SHAPES = [
+    (1, 640, 959, 64, 64),       # L0, 64-channel tiles (NB=2)
+    (1, 640, 959, 128, 64),      # L0 decoder conv on the concat input
+    (1, 320, 479, 128, 128),     # 128-channel tiles (NB=4)
+    (2, 40, 59, 1024, 1024),     # bottleneck: 8 n-tiles, 64 K-chunks, ragged 16x32 tiles
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout', CONV_SHAPES)
+def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout):
+    from unetk import ops
+    dens = min(1.0, 24.0 / (9 * cin))                   # ~24 non-zero taps per output: |y| <= 256, exact in bf16
+    x = _ints((n, h, w, cin), 1).cuda()
+    wt = _ints((cout, cin, 3, 3), 2, dens).cuda()
+    xb = x.bfloat16()
+    stats = ops.new_stats(cout, 'cuda')
+    y = ops.conv3x3_fprop(xb, ops.pack_weight(0, wt, cout, cin, torch.bfloat16), cout, stats=stats)
+    wmat = wt.reshape(cout, cin * 9).t().contiguous()
+    s1 = torch.zeros(cout, dtype=torch.float64, device='cuda')
+    s2 = torch.zeros(cout, dtype=torch.float64, device='cuda')
+    for i in range(n):
+        ref = (_im2col(x[i:i + 1]) @ wmat).reshape(h, w, cout)
+        assert ref.abs().max() <= 256
+        assert torch.equal(y[i].float(), ref), 'fprop'
+        s1 += ref.double().sum((0, 1))
+        s2 += (ref.double() ** 2).sum((0, 1))
+    got = stats.sum(0)
+    assert torch.equal(got[:, 0], s1) and torch.equal(got[:, 1], s2), 'BatchNorm statistics'
+
+    # dgrad: dx = conv(dy, rot180(w)^T)
+    dy = _ints((n, h, w, cout), 3).cuda()
+    dens_d = min(1.0, 24.0 / (9 * cout))
+    wd = _ints((cout, cin, 3, 3), 4, dens_d).cuda()
+    dx = ops.conv3x3_dgrad(dy.bfloat16(), ops.pack_weight(1, wd, cout, cin, torch.bfloat16), cin)
+    wrot = wd.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * 9).t().contiguous()
+    for i in range(n):
+        ref = (_im2col(dy[i:i + 1]) @ wrot).reshape(h, w, cin)
+        assert torch.equal(dx[i].float(), ref), 'dgrad'
+
+    # wgrad: dw[co,ci,kh,kw] = sum_pixels x[p + tap][ci] * dy[p][co]  (integers < 2^24: exact in fp32)
+    dw = torch.empty((cout, cin, 3, 3), device='cuda')
+    ops.conv3x3_wgrad(xb, dy.bfloat16(), dw)
+    ref = torch.zeros((cout, cin * 9), device='cuda')
+    for i in range(n):
+        ref += dy[i].reshape(h * w, cout).t() @ _im2col(x[i:i + 1])
+    assert ref.abs().max() < 2 ** 24
+    assert torch.equal(dw.reshape(cout, cin * 9), ref), 'wgrad'
+
+
+@pytest.mark.parametrize('n,h,w,cin', [(1, 320, 479, 128), (2, 40, 59, 1024)])
+def test_convT_fwd_dgrad_wgrad_exact_on_integers(n, h, w, cin):
+    from unetk import ops
+    cout = cin // 2
+    hs, ws = 2 * h, 2 * w + 1                           # the reference's odd widths: one F.pad column on the right
+    x = _ints((n, h, w, cin), 5).cuda()
+    wt = _ints((cin, cout, 2, 2), 6, min(1.0, 64.0 / cin)).cuda()
+    bias = _ints((cout,), 7).cuda()
+    cat = torch.full((n, hs, ws, cin), 3.0, dtype=torch.bfloat16, device='cuda')
+    ops.convT2x2_fwd(x.bfloat16(), ops.pack_weight(2, wt, cout, cin, torch.bfloat16), bias, cat, cout, cout, 0, 0)
+    ref = torch.empty((n, 2 * h, 2 * w, cout), device='cuda')          # independent evaluation: four GEMMs
+    for a in (0, 1):
+        for b in (0, 1):
+            ref[:, a::2, b::2] = torch.einsum('nijc,ck->nijk', x, wt[:, :, a, b]) + bias
+    assert ref.abs().max() <= 256
+    assert torch.equal(cat[:, :, :2 * w, cout:].float(), ref), 'convT forward'
+    assert torch.equal(cat[:, :, 2 * w:, cout:].float(), torch.zeros_like(cat[:, :, 2 * w:, cout:]).float()), 'pad'
+    assert torch.equal(cat[..., :cout].float(), torch.full_like(cat[..., :cout], 3.0).float()), 'skip half untouched'
+
+    dcat = _ints((n, hs, ws, cin), 8).cuda()
+    wd = _ints((cin, cout, 2, 2), 9, min(1.0, 16.0 / cout)).cuda()
+    dx = ops.convT2x2_dgrad(dcat.bfloat16(), cout, ops.pack_weight(3, wd, cout, cin, torch.bfloat16), cin, cout, h, w,
+                            0, 0)
+    dup = dcat[:, :, :2 * w, cout:].permute(0, 3, 1, 2).contiguous()
+    ref = sum(torch.einsum('nkij,ck->nijc', dup[:, :, a::2, b::2], wd[:, :, a, b]) for a in (0, 1) for b in (0, 1))
+    assert torch.equal(dx.float(), ref), 'convT dgrad'
+
+    dw = torch.empty_like(wt)
+    db = torch.empty(cout, device='cuda')
+    ops.convT2x2_wgrad(x.bfloat16(), dcat.bfloat16(), cout, dw, db, 0, 0)
+    # dw[ci,co,a,b] = sum_{n,i,j} x[n,i,j,ci] * dup[n,co,2i+a,2j+b]
+    ref = torch.stack([torch.stack([torch.einsum('nijc,nkij->ck', x, dup[:, :, a::2, b::2]) for b in (0, 1)], -1)
+                       for a in (0, 1)], -2)
+    assert torch.equal(dw, ref), 'convT wgrad'
+    assert torch.equal(db, dup.sum((0, 2, 3))), 'convT bias gradient'
+
+
+def test_maxpool_full_size():
+    from unetk import ops
+    n, h, w, c = 2, 640, 959, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((n, h, w, c), generator=g).cuda().bfloat16()
+    out = ops.maxpool_fwd(x)
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float(), ref)
+    dpool = _ints((n, h // 2, w // 2, c), 12).cuda().bfloat16()
+    dx = ops.maxpool_bwd(x, dpool)
+    # every pooled gradient lands on exactly one input of its window; the dropped odd column gets none
+    assert torch.equal(dx[:, :, :w - 1].float().reshape(n, h // 2, 2, w // 2, 2, c).sum((2, 4)), dpool.float())
+    assert torch.equal(dx[:, :, w - 1:].float(), torch.zeros((n, h, 1, c), device='cuda'))
+    picked = (dx != 0).float().reshape(n, h, w, c)[:, :, :w - 1].reshape(n, h // 2, 2, w // 2, 2, c).sum((2, 4))
+    assert torch.equal(picked, (dpool != 0).float())
+
+
+def test_unet_full_size_train_step_runs_and_is_finite():
+    """One bf16 training step at the benchmark's image size (batch 2): shapes, finiteness, and the fused loss equals
+    the reference's composition (train.py:102-111) evaluated by torch on the logits the network produced."""
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    from utils.dice_score import dice_loss
+    torch.manual_seed(0)
+    net = UNet(3, 2, False).cuda().to(memory_format=torch.channels_last).train()
+    img = torch.rand((2, 3, 640, 959), device='cuda').contiguous(memory_format=torch.channels_last)
+    mask = (torch.rand((2, 640, 959), device='cuda') < 0.2).long()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        logits = net(img)
+    assert logits.shape == (2, 2, 640, 959)
+    loss = segmentation_loss(logits, mask)
+    loss.backward()
+    lf = logits.detach().float()
+    ref = F.cross_entropy(lf, mask) + dice_loss(F.softmax(lf, dim=1),
+                                                F.one_hot(mask, 2).permute(0, 3, 1, 2).float(), multiclass=True)
+    assert abs(float(loss.detach()) - float(ref)) < 1e-4
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    bn = net.inc.double_conv[1]
+    assert int(bn.num_batches_tracked) == 1 and torch.isfinite(bn.running_var).all()
