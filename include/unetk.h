@@ -168,6 +168,22 @@ int unetk_dice_fwd(const float* input, const float* target, int n_groups, int64_
 int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out, float sign, int n_groups,
                    int64_t group_size, float* dinput, void* stream);
 
+/* ---- optimizer step --------------------------------------------------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
+ * torch.optim.RMSprop(lr, alpha, eps, weight_decay, momentum, centered=False).step() -- reference train.py:77-78
+ * (construction) and train.py:115-116 (use) -- for parameters, gradients and optimizer state that live in ONE
+ * flat fp32 buffer each (n elements, 16-byte aligned):
+ *   coef = min(1, max_norm / (||grad||_2 + 1e-6))  (max_norm <= 0: no clipping);  grad *= coef  (written back)
+ *   g = grad + weight_decay * param;  square_avg = alpha * square_avg + (1 - alpha) * g * g
+ *   avg = sqrt(square_avg) + eps;  momentum > 0:  buf = momentum * buf + g / avg,  param -= lr * buf
+ *                                  else:          param -= lr * g / avg
+ * workspace: unetk_clip_rmsprop_workspace_bytes() bytes; total_norm_out (device, may be NULL) receives ||grad||_2
+ * before clipping, the value clip_grad_norm_ returns. */
+int64_t unetk_clip_rmsprop_workspace_bytes(void);
+int unetk_clip_rmsprop_step(float* param, float* grad, float* square_avg, float* momentum_buf, int64_t n,
+                            void* workspace, int64_t workspace_bytes, double* total_norm_out, float max_norm, float lr,
+                            float alpha, float eps, float weight_decay, float momentum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

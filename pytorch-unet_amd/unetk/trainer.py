@@ -5,8 +5,9 @@
   weight_decay 1e-8, momentum 0.999, foreach) step.
 
 The reference's GradScaler (train.py:80,114-117) exists for fp16; BASELINE.json's configurations are bf16, whose
-range needs no loss scaling, so no scaler is used.  The optimizer step stays in PyTorch (foreach) for now
-(SURVEY.md 8f row 2); the clip is applied to the single flat gradient buffer (same arithmetic as
+range needs no loss scaling, so no scaler is used.  Clip + RMSprop run as one fused pass over the flat gradient /
+parameter / state buffers (unetk.optim.ClipRMSprop); `fused_optimizer=False` keeps torch's
+foreach RMSprop with the clip applied to the flat gradient buffer (same arithmetic as
 torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1).
 """
 import torch
@@ -17,13 +18,19 @@ from .loss import segmentation_loss
 
 class Trainer:
     def __init__(self, net, learning_rate=1e-5, weight_decay=1e-8, momentum=0.999, gradient_clipping=1.0, amp=True,
-                 process_group=None, bucket_bytes=25 << 20):
+                 process_group=None, bucket_bytes=25 << 20, fused_optimizer=True):
         self.net = net
         self.amp = amp
         self.clip = gradient_clipping
-        self.optimizer = torch.optim.RMSprop(net.parameters(), lr=learning_rate, weight_decay=weight_decay,
-                                             momentum=momentum, foreach=True)
         self.sync = FlatGrads(net, process_group, bucket_bytes)
+        self.fused = fused_optimizer
+        if fused_optimizer:
+            from .optim import ClipRMSprop
+            self.optimizer = ClipRMSprop(self.sync, lr=learning_rate, weight_decay=weight_decay, momentum=momentum,
+                                         max_norm=gradient_clipping)
+        else:
+            self.optimizer = torch.optim.RMSprop(net.parameters(), lr=learning_rate, weight_decay=weight_decay,
+                                                 momentum=momentum, foreach=True)
 
     def step(self, images, true_masks):
         """One optimisation step; returns the (device) loss tensor without forcing a host sync."""
@@ -36,7 +43,7 @@ class Trainer:
         loss.backward()
         self.sync.finish()
         flat = self.sync.flat
-        if self.clip is not None and flat is not None:
+        if not self.fused and self.clip is not None and flat is not None:
             total_norm = torch.linalg.vector_norm(flat)
             flat.mul_(torch.clamp(self.clip / (total_norm + 1e-6), max=1.0))
         self.optimizer.step()

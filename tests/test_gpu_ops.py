@@ -318,3 +318,34 @@ def test_dice_kernels():
     z = torch.zeros((2, 5, 6), device='cuda')
     dz, _ = ops.dice_fwd(z, z, 1, 60, 1e-6, False)
     assert float(dz) == 1.0
+
+
+# ------------------------------------------------------------------------------------- optimizer step (8f row 2)
+@pytest.mark.parametrize('momentum,weight_decay,max_norm', [(0.999, 1e-8, 1.0), (0.0, 0.0, 1.0), (0.9, 1e-2, None)])
+def test_clip_rmsprop_matches_torch(momentum, weight_decay, max_norm):
+    """unetk_clip_rmsprop_step against torch.nn.utils.clip_grad_norm_ + torch.optim.RMSprop (what train.py:77-78,
+    115-116 run), three steps, on a flat buffer with an odd length (vector body + scalar tail)."""
+    import ctypes
+    from unetk._native import fn, check, stream_ptr
+    n = 4 * 50_000 + 3
+    g = torch.Generator().manual_seed(21)
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.RMSprop([ref_p], lr=1e-3, weight_decay=weight_decay, momentum=momentum)
+    p = p0.clone().cuda()
+    sq = torch.zeros(n, device='cuda')
+    buf = torch.zeros(n, device='cuda')
+    ws = torch.empty(int(fn['unetk_clip_rmsprop_workspace_bytes']()), dtype=torch.uint8, device='cuda')
+    norm = torch.zeros((), dtype=torch.float64, device='cuda')
+    for step in range(3):
+        grad = torch.randn(n, generator=g) * (3.0 if step == 0 else 1e-3)     # first step clips, later ones do not
+        ref_p.grad = grad.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([ref_p], max_norm) if max_norm is not None else grad.norm()
+        opt.step()
+        gd = grad.cuda()
+        check(fn['unetk_clip_rmsprop_step'](p.data_ptr(), gd.data_ptr(), sq.data_ptr(), buf.data_ptr(), n, ws.data_ptr(),
+                                            ws.numel(), norm.data_ptr(), float(max_norm or 0.0), 1e-3, 0.99, 1e-8,
+                                            weight_decay, momentum, stream_ptr()), 'unetk_clip_rmsprop_step')
+        assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
+        assert rel_err(gd.cpu().numpy(), ref_p.grad.numpy()) < 1e-5            # clipped gradient written back
+        assert rel_err(p.cpu().numpy(), ref_p.detach().numpy()) < 1e-5

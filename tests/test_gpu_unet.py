@@ -263,3 +263,34 @@ def test_hubconf_entry():
     assert (net.n_channels, net.n_classes, net.bilinear) == (3, 2, False)
     with pytest.raises(TypeError):
         net.use_checkpointing()
+
+
+def test_trainer_fused_optimizer_matches_foreach_rmsprop():
+    """Two Trainer steps with the fused clip+RMSprop (flat buffers) against torch's foreach RMSprop + flat clip on an
+    identically initialised net: same parameters afterwards, parameters still the nn.Parameter objects of the module
+    (state_dict contract), LR changes through param_groups are honoured."""
+    from unet import UNet
+    from unetk.trainer import Trainer
+    img = cl(wave('trainer.img', (2, 3, 48, 64), 0.5, 0.5))
+    mask = torch.from_numpy(W.int_wave('trainer.mask', (2, 48, 64), 2)).cuda()
+    nets = [load_closed_form(UNet(3, 2, False)).cuda().train() for _ in range(2)]
+    trainers = [Trainer(nets[0], amp=False, learning_rate=1e-3, fused_optimizer=True),
+                Trainer(nets[1], amp=False, learning_rate=1e-3, fused_optimizer=False)]
+    keys_before = [k for k, _ in nets[0].named_parameters()]
+    for step in range(2):
+        for t in trainers:
+            t.optimizer.param_groups[0]['lr'] = 1e-3 if step == 0 else 5e-4
+        losses = [float(t.step(img, mask)) for t in trainers]
+        assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[1])
+    assert [k for k, _ in nets[0].named_parameters()] == keys_before
+    pa, pb = dict(nets[0].named_parameters()), dict(nets[1].named_parameters())
+    for k in pa:
+        assert pa[k].shape == pb[k].shape
+        # RMSprop's first steps move every element by ~lr/sqrt(1-alpha) * sign(g): elements whose gradient is at the
+        # rounding noise of the two (atomically ordered) backward passes may step differently, so compare in L2
+        # (the arithmetic itself is pinned element-wise by test_gpu_ops.py::test_clip_rmsprop_matches_torch)
+        # ... and the second step's gradients inherit that difference; the losses above agree to 1e-5
+        assert l2_err(npy(pa[k]), npy(pb[k])) < 5e-3, k
+    assert float(trainers[0].optimizer.total_norm) > 0
+    sd = nets[0].state_dict()
+    assert sd['inc.double_conv.0.weight'].data_ptr() == nets[0].inc.double_conv[0].weight.data_ptr()
