@@ -168,6 +168,17 @@ int unetk_dice_fwd(const float* input, const float* target, int n_groups, int64_
 int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out, float sign, int n_groups,
                    int64_t group_size, float* dinput, void* stream);
 
+/* ---- validation metric ------------------------------------------------------------------
+ * Replaces reference evaluate.py:31-36 for n_classes > 1:
+ *   mask_true = one_hot(mask_true); mask_pred = one_hot(logits.argmax(1));
+ *   multiclass_dice_coeff(mask_pred[:, first_class:], mask_true[:, first_class:], reduce_batch_first=False)
+ * as one pass of integer counting + a finalize: one dice per (image, class >= first_class) with dice_coeff's
+ * empty-set rule (dice_score.py:14), mean over the groups -> dice_out[0].  logits: NHWC [n][hw][ld >= n_classes],
+ * bf16 or fp32; mask: int64 [n][hw] with values in [0, n_classes) (values outside count for no class). */
+int64_t unetk_eval_dice_workspace_bytes(int n, int n_classes);
+int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
+                    float eps, void* workspace, int64_t workspace_bytes, float* dice_out, int dtype, void* stream);
+
 /* ---- optimizer step --------------------------------------------------------------------
  * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
  * torch.optim.RMSprop(lr, alpha, eps, weight_decay, momentum, centered=False).step() -- reference train.py:77-78

@@ -268,6 +268,35 @@ for tag, (ncls, bil, shape) in {
             arrs['logits_eval_bf16'] = npy(net(img))
     save(tag, **arrs)
 
+# ------------------------------------------------------------------ 5. validation round (evaluate.py:8-40)
+from evaluate import evaluate as ref_evaluate   # noqa: E402  (reference module; imports tqdm only)
+
+for tag, (ncls, shape) in {'eval_c2': (2, (2, 3, 96, 142)), 'eval_c21': (21, (2, 3, 64, 80))}.items():
+    net = UNet(3, ncls, False)
+    load_closed_form(net)
+    batches = []
+    for b in range(2):
+        img = t(f'{tag}.img{b}', shape, 0.5, 0.5, dtype=torch.float32)
+        mask = torch.from_numpy(W.int_wave(f'{tag}.mask{b}', (shape[0],) + shape[2:], ncls))
+        batches.append({'image': img, 'mask': mask})
+    score = ref_evaluate(net, batches, torch.device('cpu'), False)
+    assert net.training                                   # evaluate() restores train mode (evaluate.py:39)
+    # how close to a tie the argmax decisions are: second-best margin quantiles, for the tolerance of the GPU test
+    net.eval()
+    with torch.no_grad():
+        top2 = net(batches[0]['image']).topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).flatten()
+    save(tag, dice=npy(score), margin_q01=np.array(float(margin.quantile(0.01))),
+         n_batches=np.array(len(batches)))
+try:                                                      # n_classes == 1: the reference's own evaluate() asserts
+    net1 = load_closed_form(UNet(3, 1, False))
+    ref_evaluate(net1, [{'image': t('eval_c1.img', (1, 3, 32, 48), 0.5, 0.5, dtype=torch.float32),
+                         'mask': torch.zeros((1, 32, 48), dtype=torch.long)}], torch.device('cpu'), False)
+    c1 = 'returned'
+except AssertionError:
+    c1 = 'AssertionError'
+save('eval_c1_behaviour', raised=np.array(c1))
+
 # checkpoint file shaped like train.py:163-165 writes it (state_dict + 'mask_values'), tiny variant
 # is impossible (widths are hard-coded), so only the key manifest above pins the layout.
 print('done')

@@ -190,6 +190,70 @@ __global__ void dice_bwd_kernel(const float* __restrict__ t, const float* __rest
     dx[g * group_size + i] = a * t[g * group_size + i] + b;
 }
 
+// ------------------------------------------------------------------------------------------ evaluation metric
+// evaluate.py:31-36 in one pass: pred = argmax_c logits (first maximum, like torch.argmax), then per (image, class)
+//   inter = #{pred == c and true == c},  npred = #{pred == c},  ntrue = #{true == c}
+// Integer counts (wave ballots, no float atomics): exact and order independent.
+template <typename T>
+__global__ __launch_bounds__(256) void eval_counts_kernel(const T* __restrict__ logits, int ld, const long long* __restrict__ mask,
+                                                          long hw, int C, unsigned long long* __restrict__ counts) {
+  extern __shared__ unsigned cnt[];           // [4 waves][C][3]
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * C * 3; i += 256) cnt[i] = 0u;
+  __syncthreads();
+  unsigned* mine = cnt + wid * C * 3;
+  const T* lg = logits + (size_t)n * hw * ld;
+  const long long* mk = mask + (size_t)n * hw;
+  for (long p0 = (long)blockIdx.x * 256 + wid * 64; p0 < hw; p0 += (long)gridDim.x * 256) {
+    const long p = p0 + lane;
+    int pred = -1, tru = -1;
+    if (p < hw) {
+      const T* row = lg + p * ld;
+      float best = to_f32(row[0]);
+      pred = 0;
+      for (int c = 1; c < C; ++c) {
+        const float v = to_f32(row[c]);
+        if (v > best) { best = v; pred = c; }
+      }
+      tru = (int)mk[p];
+    }
+    for (int c = 0; c < C; ++c) {
+      const unsigned long long bp = __ballot(pred == c), bt = __ballot(tru == c);
+      if (lane == 0) {
+        mine[c * 3 + 0] += __popcll(bp & bt);
+        mine[c * 3 + 1] += __popcll(bp);
+        mine[c * 3 + 2] += __popcll(bt);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 3; i += 256) {
+    const unsigned v = cnt[i] + cnt[C * 3 + i] + cnt[2 * C * 3 + i] + cnt[3 * C * 3 + i];
+    if (v) atomicAdd(counts + (size_t)n * C * 3 + i, (unsigned long long)v);
+  }
+}
+
+// multiclass_dice_coeff(one_hot(pred)[:, 1:], one_hot(true)[:, 1:], reduce_batch_first=False)  (evaluate.py:36,
+// dice_score.py:5-22): one dice per (image, class >= first_class), sets == 0 -> dice 1, mean over the groups
+__global__ void eval_dice_finalize_kernel(const unsigned long long* __restrict__ counts, int N, int C, int first_class,
+                                          float eps, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0;
+  int groups = 0;
+  for (int n = 0; n < N; ++n)
+    for (int c = first_class; c < C; ++c) {
+      const unsigned long long* k = counts + ((size_t)n * C + c) * 3;
+      const float inter = 2.f * (float)k[0];
+      float sets = (float)k[1] + (float)k[2];
+      if (sets == 0.f) sets = inter;
+      acc += (double)((inter + eps) / (sets + eps));
+      ++groups;
+    }
+  out[0] = groups ? (float)(acc / groups) : 0.f;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -258,6 +322,40 @@ int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out
   if (gx > cap) gx = cap;
   hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)gx, (unsigned)n_groups), dim3(256), 0, (hipStream_t)stream, target,
                      coef, grad_out, sign, (long)group_size, dinput);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int64_t unetk_eval_dice_workspace_bytes(int n, int n_classes) {
+  if (n <= 0 || n_classes <= 0) return UNETK_ERR_SHAPE;
+  return (int64_t)n * n_classes * 3 * sizeof(unsigned long long);
+}
+
+int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
+                    float eps, void* workspace, int64_t workspace_bytes, float* dice_out, int dtype, void* stream) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!logits || !mask || !workspace || !dice_out) return UNETK_ERR_ARG;
+  if (n <= 0 || n > 65535 || hw <= 0 || n_classes < 2 || n_classes > 1024 || ld < n_classes || first_class < 0 ||
+      first_class >= n_classes)
+    return UNETK_ERR_SHAPE;
+  if (workspace_bytes < unetk_eval_dice_workspace_bytes(n, n_classes)) return UNETK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)n * n_classes * 3 * sizeof(unsigned long long), s) != hipSuccess)
+    return UNETK_ERR_LAUNCH;
+  long gx = (hw + 255) / 256;
+  const long cap = n >= 2048 ? 1 : 2048 / n;
+  if (gx > cap) gx = cap;
+  const size_t lds = (size_t)4 * n_classes * 3 * sizeof(unsigned);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(eval_counts_kernel<bf16>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s, (const bf16*)logits,
+                       ld, (const long long*)mask, (long)hw, n_classes, (unsigned long long*)workspace);
+  else
+    hipLaunchKernelGGL(eval_counts_kernel<float>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s,
+                       (const float*)logits, ld, (const long long*)mask, (long)hw, n_classes,
+                       (unsigned long long*)workspace);
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(eval_dice_finalize_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)workspace, n,
+                     n_classes, first_class, eps, dice_out);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -18,7 +18,7 @@ from . import ops
 def activation_dtype(x):
     """bf16 under torch.autocast (the reference's --amp path, train.py:100), otherwise the input's dtype."""
     if torch.is_autocast_enabled():
-        dt = torch.get_autocast_gpu_dtype()
+        dt = torch.get_autocast_dtype('cuda')
         if dt != torch.bfloat16:
             raise RuntimeError('the MI355X kernels implement bf16 and fp32; use torch.autocast(dtype=torch.bfloat16)')
         return dt

@@ -380,3 +380,24 @@ def dice_bwd(tgt, coef, grad_out, sign, n_groups, group_size):
     check(fn['unetk_dice_bwd'](tgt.data_ptr(), coef.data_ptr(), _ptr(grad_out), sign, n_groups, group_size,
                                dx.data_ptr(), stream_ptr()), 'unetk_dice_bwd')
     return dx
+
+
+# ------------------------------------------------------------------------------------ validation metric
+def eval_dice(logits, mask, first_class=1, eps=1e-6):
+    """multiclass Dice of argmax(logits) against an int64 mask, classes >= first_class (evaluate.py:31-36).
+    logits: [N,C,H,W] (any memory format; read as NHWC) bf16/fp32; mask: [N,H,W] int64.  Returns a 0-dim fp32 tensor."""
+    require_cuda(logits, mask)
+    if logits.dim() != 4 or mask.dim() != 3 or mask.dtype != torch.int64 or \
+            (logits.shape[0],) + tuple(logits.shape[2:]) != tuple(mask.shape):
+        raise RuntimeError('eval_dice: logits [N,C,H,W] and an int64 mask [N,H,W] are required')
+    x = to_nhwc(logits)
+    n, h, w, c, ld = nhwc_meta(x, 'eval_dice logits')
+    m = mask.contiguous()
+    need = fn['unetk_eval_dice_workspace_bytes'](n, c)
+    if need < 0:
+        check(int(need), 'unetk_eval_dice_workspace_bytes')
+    ws = workspace(need, x.device, tag='eval')
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(fn['unetk_eval_dice'](x.data_ptr(), ld, m.data_ptr(), n, h * w, c, first_class, eps, ws.data_ptr(), ws.numel(),
+                                out.data_ptr(), dtype_code(x.dtype), stream_ptr()), 'unetk_eval_dice')
+    return out.reshape(())

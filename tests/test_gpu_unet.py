@@ -294,3 +294,54 @@ def test_trainer_fused_optimizer_matches_foreach_rmsprop():
     assert float(trainers[0].optimizer.total_norm) > 0
     sd = nets[0].state_dict()
     assert sd['inc.double_conv.0.weight'].data_ptr() == nets[0].inc.double_conv[0].weight.data_ptr()
+
+
+# ------------------------------------------------------------------------------------- validation round (8f row 1)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c,h,w', [(2, 2, 17, 23), (3, 21, 31, 45), (1, 5, 64, 70)])
+def test_eval_dice_matches_reference_composition(dtype, n, c, h, w):
+    """unetk_eval_dice against the reference's one_hot/argmax/multiclass_dice_coeff chain (evaluate.py:31-36),
+    including ties (first maximum wins), an image without foreground, and a class that is never predicted."""
+    import torch.nn.functional as F
+    from unetk import ops
+    from utils.dice_score import multiclass_dice_coeff
+    g = torch.Generator().manual_seed(n * 100 + c)
+    logits = (torch.randn((n, c, h, w), generator=g) * 2).round().to(dtype).cuda()      # rounded: many exact ties
+    logits = logits.contiguous(memory_format=torch.channels_last)
+    mask = torch.randint(0, c, (n, h, w), generator=g).cuda()
+    mask[0] = 0                                                                          # background only
+    got = ops.eval_dice(logits, mask, first_class=1)
+    mt = F.one_hot(mask, c).permute(0, 3, 1, 2).float()
+    mp = F.one_hot(logits.float().argmax(dim=1), c).permute(0, 3, 1, 2).float()
+    ref = multiclass_dice_coeff(mp[:, 1:].contiguous(), mt[:, 1:].contiguous(), reduce_batch_first=False)
+    assert abs(float(got) - float(ref)) < 1e-6
+
+
+@pytest.mark.parametrize('tag,ncls,shape', [('eval_c2', 2, (2, 3, 96, 142)), ('eval_c21', 21, (2, 3, 64, 80))])
+def test_evaluate_matches_reference(tag, ncls, shape):
+    from unet import UNet
+    from evaluate import evaluate
+    g = golden(tag)
+    net = load_closed_form(UNet(3, ncls, False)).cuda().train()
+    batches = [{'image': wave(f'{tag}.img{b}', shape, 0.5, 0.5),
+                'mask': torch.from_numpy(W.int_wave(f'{tag}.mask{b}', (shape[0],) + shape[2:], ncls))}
+               for b in range(int(g['n_batches']))]
+    score = evaluate(net, batches, torch.device('cuda'), False)
+    assert net.training
+    # fp32 logits agree to ~1e-5 and 99 % of the argmax margins exceed margin_q01 >> that, so hardly a pixel can flip
+    assert float(g['margin_q01']) > 1e-3
+    assert abs(float(score) - float(g['dice'])) <= 2e-3 * max(float(g['dice']), 1e-3)
+    bf = evaluate(net, batches, torch.device('cuda'), True)                              # bf16 autocast path runs
+    assert 0.0 <= float(bf) <= 1.0
+
+
+def test_evaluate_binary_net_asserts_like_the_reference():
+    """evaluate.py:26-29 hands the un-squeezed [N,1,H,W] prediction to dice_coeff, whose size assertion fires
+    (fixture eval_c1_behaviour records it from the reference itself)."""
+    from unet import UNet
+    from evaluate import evaluate
+    assert str(golden('eval_c1_behaviour')['raised']) == 'AssertionError'
+    net = load_closed_form(UNet(3, 1, False)).cuda()
+    batch = [{'image': wave('eval_c1.img', (1, 3, 32, 48), 0.5, 0.5), 'mask': torch.zeros((1, 32, 48), dtype=torch.long)}]
+    with pytest.raises(AssertionError):
+        evaluate(net, batch, torch.device('cuda'), False)
