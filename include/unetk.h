@@ -179,6 +179,13 @@ int64_t unetk_eval_dice_workspace_bytes(int n, int n_classes);
 int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
                     float eps, void* workspace, int64_t workspace_bytes, float* dice_out, int dtype, void* stream);
 
+/* ---- prediction mask --------------------------------------------------------------------
+ * Replaces reference predict.py:26-31: F.interpolate(output, (out_h, out_w), mode='bilinear') (align_corners=False)
+ * followed by output.argmax(dim=1) (n_classes > 1) or torch.sigmoid(output) > threshold (n_classes == 1), fused;
+ * logits NHWC [n][h][w][ld >= n_classes] bf16/fp32 -> mask int64 [n][out_h][out_w]. */
+int unetk_predict_mask(const void* logits, int ld, int n, int h, int w, int n_classes, int out_h, int out_w,
+                       float threshold, int64_t* mask, int dtype, void* stream);
+
 /* ---- optimizer step --------------------------------------------------------------------
  * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
  * torch.optim.RMSprop(lr, alpha, eps, weight_decay, momentum, centered=False).step() -- reference train.py:77-78

@@ -297,6 +297,31 @@ except AssertionError:
     c1 = 'AssertionError'
 save('eval_c1_behaviour', raised=np.array(c1))
 
+# ------------------------------------------------------------------ 6. predict_img (predict.py:15-33)
+# predict.py itself cannot be imported here (it imports torchvision, absent offline): its body is run line by line
+# on the reference's own net and BasicDataset.preprocess (importable).
+from PIL import Image   # noqa: E402
+from utils.data_loading import BasicDataset as RefDataset   # noqa: E402
+
+for tag, ncls in {'predict_c2': 2, 'predict_c1': 1}.items():
+    net = load_closed_form(UNet(3, ncls, False))
+    rgb = (W.wave(tag + '.rgb', (70, 101, 3), 0.5, 0.5) * 255).astype(np.uint8)           # H=70, W=101 "photo"
+    full_img = Image.fromarray(rgb)
+    net.eval()
+    img = torch.from_numpy(RefDataset.preprocess(None, full_img, 0.5, is_mask=False))    # predict.py:21
+    img = img.unsqueeze(0).to(dtype=torch.float32)
+    with torch.no_grad():
+        output = net(img)
+        up = F.interpolate(output, (full_img.size[1], full_img.size[0]), mode='bilinear')  # predict.py:27
+        mask = up.argmax(dim=1) if ncls > 1 else torch.sigmoid(up) > 0.5                   # predict.py:28-31
+    out = mask[0].long().squeeze().numpy()
+    if ncls > 1:
+        top2 = up.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])[0].numpy()
+    else:
+        margin = (torch.sigmoid(up) - 0.5).abs()[0, 0].numpy()
+    save(tag, rgb=rgb, preprocessed=img[0].numpy(), mask=out.astype(np.int64), margin=margin.astype(np.float32))
+
 # checkpoint file shaped like train.py:163-165 writes it (state_dict + 'mask_values'), tiny variant
 # is impossible (widths are hard-coded), so only the key manifest above pins the layout.
 print('done')

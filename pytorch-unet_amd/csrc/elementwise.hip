@@ -522,6 +522,40 @@ __global__ void zero_border_kernel(T* buf, int ld, int N, int Hs, int Ws, int C,
   }
 }
 
+// ------------------------------------------------------------------------------------------ prediction mask
+// predict.py:26-31 in one pass: F.interpolate(logits, (H, W), mode='bilinear') [align_corners=False: src =
+// (dst + 0.5) * in/out - 0.5 clamped at 0, aten upsample_bilinear2d's weights and summation order], then argmax over
+// the classes (first maximum) or sigmoid(x) > threshold for a single class.  One thread per output pixel.
+template <typename T>
+__global__ void predict_mask_kernel(const T* __restrict__ logits, int ld, int N, int h, int w, int C, int H, int W,
+                                    float threshold, long long* __restrict__ mask) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const long total = (long)N * H * W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(idx % W);
+    const long r = idx / W;
+    const int Y = (int)(r % H);
+    const long n = r / H;
+    const float fy = fmaxf(sy * ((float)Y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float)X + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const T* img = logits + (size_t)n * h * w * ld;
+    const T* p00 = img + ((size_t)y0 * w + x0) * ld;
+    const T* p01 = img + ((size_t)y0 * w + x1) * ld;
+    const T* p10 = img + ((size_t)y1 * w + x0) * ld;
+    const T* p11 = img + ((size_t)y1 * w + x1) * ld;
+    float best = 0.f;
+    long long arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = ly0 * (lx0 * to_f32(p00[c]) + lx1 * to_f32(p01[c])) + ly1 * (lx0 * to_f32(p10[c]) + lx1 * to_f32(p11[c]));
+      if (c == 0 || v > best) { best = v; arg = c; }
+    }
+    if (C == 1) arg = (1.f / (1.f + expf(-best))) > threshold ? 1 : 0;
+    mask[idx] = arg;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ channel sums
 // out[c] = sum over a window of the image of x[n,y,x,c]   (bias gradient of ConvTranspose2d, unet_parts.py:53)
 template <typename T>
@@ -783,6 +817,18 @@ int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int w
                                        win_y, win_x, win_h, win_w, scratch));
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(double_to_float_kernel, dim3((c + 255) / 256), dim3(256), 0, s, (const double*)scratch, out, c);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+int unetk_predict_mask(const void* logits, int ld, int n, int h, int w, int n_classes, int out_h, int out_w,
+                       float threshold, int64_t* mask, int dtype, void* stream) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!logits || !mask) return UNETK_ERR_ARG;
+  if (n <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || ld < n_classes || out_h <= 0 || out_w <= 0) return UNETK_ERR_SHAPE;
+  const long total = (long)n * out_h * out_w;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(predict_mask_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)logits, ld, n, h, w, n_classes, out_h, out_w, threshold,
+                                       (long long*)mask));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

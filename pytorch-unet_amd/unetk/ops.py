@@ -401,3 +401,18 @@ def eval_dice(logits, mask, first_class=1, eps=1e-6):
     check(fn['unetk_eval_dice'](x.data_ptr(), ld, m.data_ptr(), n, h * w, c, first_class, eps, ws.data_ptr(), ws.numel(),
                                 out.data_ptr(), dtype_code(x.dtype), stream_ptr()), 'unetk_eval_dice')
     return out.reshape(())
+
+
+# ------------------------------------------------------------------------------------ prediction mask
+def predict_mask(logits, out_h, out_w, threshold=0.5):
+    """F.interpolate(logits, (out_h, out_w), mode='bilinear') then argmax (C > 1) or sigmoid > threshold (C == 1),
+    fused (predict.py:26-31).  logits [N,C,h,w] bf16/fp32 -> int64 [N,out_h,out_w]."""
+    require_cuda(logits)
+    if logits.dim() != 4:
+        raise RuntimeError('predict_mask: logits [N,C,h,w] required')
+    x = to_nhwc(logits)
+    n, h, w, c, ld = nhwc_meta(x, 'predict_mask logits')
+    mask = torch.empty((n, out_h, out_w), dtype=torch.int64, device=x.device)
+    check(fn['unetk_predict_mask'](x.data_ptr(), ld, n, h, w, c, out_h, out_w, float(threshold), mask.data_ptr(),
+                                   dtype_code(x.dtype), stream_ptr()), 'unetk_predict_mask')
+    return mask

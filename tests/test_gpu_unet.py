@@ -345,3 +345,64 @@ def test_evaluate_binary_net_asserts_like_the_reference():
     batch = [{'image': wave('eval_c1.img', (1, 3, 32, 48), 0.5, 0.5), 'mask': torch.zeros((1, 32, 48), dtype=torch.long)}]
     with pytest.raises(AssertionError):
         evaluate(net, batch, torch.device('cuda'), False)
+
+
+# ------------------------------------------------------------------------------------- predict_img (8f row 3)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,c,h,w,oh,ow', [(1, 2, 35, 50, 70, 101), (2, 21, 16, 23, 40, 31), (1, 1, 20, 20, 57, 64),
+                                           (1, 3, 30, 40, 15, 20)])
+def test_predict_mask_matches_interpolate_argmax(dtype, n, c, h, w, oh, ow):
+    """unetk_predict_mask against F.interpolate(bilinear) + argmax / sigmoid > 0.5 (predict.py:27-31) evaluated by
+    torch on the CPU in fp32; pixels may differ only where the decision margin is at rounding level."""
+    import torch.nn.functional as F
+    from unetk import ops
+    g = torch.Generator().manual_seed(7 * c + h)
+    logits = torch.randn((n, c, h, w), generator=g).to(dtype)
+    got = ops.predict_mask(logits.cuda().contiguous(memory_format=torch.channels_last), oh, ow, 0.5).cpu()
+    up = F.interpolate(logits.float(), (oh, ow), mode='bilinear')
+    if c > 1:
+        ref = up.argmax(dim=1)
+        top2 = up.topk(2, dim=1).values
+        margin = top2[:, 0] - top2[:, 1]
+    else:
+        ref = (torch.sigmoid(up) > 0.5)[:, 0].long()
+        margin = up.abs()[:, 0]
+    bad = got != ref
+    assert bad.float().mean() < 1e-3
+    assert (margin[bad] < 1e-5).all()
+
+
+@pytest.mark.parametrize('tag,ncls', [('predict_c2', 2), ('predict_c1', 1)])
+def test_predict_img_matches_reference(tag, ncls):
+    from PIL import Image
+    from unet import UNet
+    from predict import predict_img, mask_to_image
+    from utils.data_loading import BasicDataset
+    g = golden(tag)
+    full_img = Image.fromarray(g['rgb'])
+    pre = BasicDataset.preprocess(None, full_img, 0.5, is_mask=False)
+    assert pre.shape == g['preprocessed'].shape and np.abs(pre - g['preprocessed']).max() < 1e-6
+    net = load_closed_form(UNet(3, ncls, False)).cuda()
+    mask = predict_img(net, full_img, torch.device('cuda'), scale_factor=0.5, out_threshold=0.5)
+    assert mask.shape == g['mask'].shape == (70, 101) and mask.dtype == np.int64
+    bad = mask != g['mask']
+    assert bad.mean() < 2e-3
+    assert (g['margin'][bad] < 1e-3).all()           # only near-ties of the fp32 logits (1e-5 relative) may flip
+    img = mask_to_image(mask, [0, 1])
+    assert img.size == (101, 70) and img.mode == '1'
+    assert mask_to_image(mask, [[0, 0, 0], [255, 255, 255]]).mode == 'RGB'
+
+
+def test_preprocess_mask_and_errors():
+    from PIL import Image
+    from utils.data_loading import BasicDataset
+    m = np.zeros((10, 12), dtype=np.uint8)
+    m[2:6, 3:9] = 255
+    out = BasicDataset.preprocess([0, 255], Image.fromarray(m), 0.5, is_mask=True)
+    assert out.shape == (5, 6) and out.dtype == np.int64 and set(np.unique(out)) == {0, 1}
+    rgb = np.zeros((10, 12, 3), dtype=np.uint8)
+    rgb[..., 0] = 200
+    out = BasicDataset.preprocess([[0, 0, 0], [200, 0, 0]], Image.fromarray(rgb), 1.0, is_mask=True)
+    assert (out == 1).all()
+    with pytest.raises(AssertionError):
+        BasicDataset.preprocess(None, Image.fromarray(m), 0.01, is_mask=False)
