@@ -65,6 +65,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline int host_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is a PER-DEVICE
+// property of the function: remember it per call site and per device (a process may drive several GPUs).
+static inline bool unetk_allow_lds(unsigned long long* done_mask, const void* func, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+  const unsigned long long bit = 1ull << dev;
+  if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return true;
+  if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+  return true;
+}
+#define UNETK_ALLOW_LDS(func, bytes)                                                              \
+  do {                                                                                            \
+    static unsigned long long lds_ok_ = 0;                                                        \
+    if (!unetk_allow_lds(&lds_ok_, reinterpret_cast<const void*>(func), (bytes))) return UNETK_ERR_LAUNCH; \
+  } while (0)
+
 #define UNETK_CHECK_LAUNCH()                         \
   do {                                               \
     hipError_t e_ = hipGetLastError();               \

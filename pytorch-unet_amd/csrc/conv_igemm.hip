@@ -550,13 +550,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
 
 template <typename T, int NB, int KS, int NW, int MB = 2> int launch_db(const ConvParams& P, hipStream_t s) {
   constexpr size_t lds = 2 * ((size_t)(((MB * NW + 2) * 34 * 2 * KS + 63) / 64) * 1024 + 9 * KS * NB * 1024);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_db_kernel<T, NB, KS, NW, MB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return UNETK_ERR_LAUNCH;
-    attr_done = true;
-  }
+  UNETK_ALLOW_LDS((conv3x3_db_kernel<T, NB, KS, NW, MB>), lds);
   ConvParams Q = P;
   Q.tiles_y = host_cdiv(P.H, MB * NW);
   const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
@@ -784,13 +778,7 @@ __global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
 
 template <typename T, int MODE> int launch_pw(const ConvParams& P, hipStream_t s) {
   constexpr size_t lds = 2 * (64 * 1024 + 16 * 1024);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pw_db_kernel<T, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return UNETK_ERR_LAUNCH;
-    attr_done = true;
-  }
+  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE>), lds);
   ConvParams Q = P;
   Q.n_tiles = P.Cout / 128;
   const long npix = (long)P.N * P.H * P.W;
@@ -821,13 +809,7 @@ template <typename T, int NB, int MODE> size_t lds_bytes() {
 
 template <typename T, int NB, int MODE> int launch(const ConvParams& P, hipStream_t s) {
   const size_t lds = lds_bytes<T, NB, MODE>();
-  static bool attr_done = false;   // benign race: idempotent
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, NB, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return UNETK_ERR_LAUNCH;
-    attr_done = true;
-  }
+  UNETK_ALLOW_LDS((conv_igemm_kernel<T, NB, MODE>), lds);
   // tiles per workgroup: enough K-iterations per workgroup (>= ~12 chunks) to amortise the pipeline fill, as long
   // as the grid still holds >= ~8 workgroups per CU
   ConvParams Q = P;

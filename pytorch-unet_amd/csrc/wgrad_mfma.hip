@@ -639,13 +639,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     Q.row_tiles = c_in / 32; Q.col_tiles = c_out / 32;
     Q.nsplit = pick_nsplit(Q.ntiles, Q.row_tiles * Q.col_tiles);
     const size_t ldsq = 10 * 36 * 128 + 256 * 128;
-    static bool attr_q = false;
-    if (!attr_q) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess)
-        return UNETK_ERR_LAUNCH;
-      attr_q = true;
-    }
+    UNETK_ALLOW_LDS((wgrad_f32_kernel<0>), ldsq);
     hipLaunchKernelGGL(wgrad_f32_kernel<0>, dim3(Q.row_tiles * Q.col_tiles * Q.nsplit), dim3(256), ldsq,
                        (hipStream_t)stream, Q);
     UNETK_CHECK_LAUNCH();
@@ -663,13 +657,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
   P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
   P.dbg = getenv("UNETK_WGRAD_DBG") ? atoi(getenv("UNETK_WGRAD_DBG")) : 0;
   const size_t lds = 2 * W3_BUF;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_bf16_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return UNETK_ERR_LAUNCH;
-    attr_done = true;
-  }
+  UNETK_ALLOW_LDS((wgrad3_bf16_kernel), lds);
   hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                      (hipStream_t)stream, P);
   UNETK_CHECK_LAUNCH();
@@ -700,13 +688,7 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
     Q.row_tiles = c_out / 32; Q.col_tiles = c_in / 32;
     Q.nsplit = pick_nsplit(Q.ntiles, Q.row_tiles * Q.col_tiles);
     const size_t ldsq = 10 * 36 * 128 + 256 * 128;
-    static bool attr_q = false;
-    if (!attr_q) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f32_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess)
-        return UNETK_ERR_LAUNCH;
-      attr_q = true;
-    }
+    UNETK_ALLOW_LDS((wgrad_f32_kernel<1>), ldsq);
     hipLaunchKernelGGL(wgrad_f32_kernel<1>, dim3(Q.row_tiles * Q.col_tiles * Q.nsplit), dim3(256), ldsq,
                        (hipStream_t)stream, Q);
     UNETK_CHECK_LAUNCH();
@@ -723,13 +705,7 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
   P.row_tiles = c_out / 64; P.col_tiles = c_in / 64;
   P.nsplit = pick_nsplit(P.ntiles, P.row_tiles * P.col_tiles);
   const size_t lds = 10 * 36 * 128 + 256 * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return UNETK_ERR_LAUNCH;
-    attr_done = true;
-  }
+  UNETK_ALLOW_LDS((wgrad_bf16_kernel<1>), lds);
   hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
                      (hipStream_t)stream, P);
   UNETK_CHECK_LAUNCH();
