@@ -112,6 +112,11 @@ int unetk_bn_eval_params(const float* gamma, const float* beta, const float* run
 /* out = relu(y*scale + shift) */
 int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
                         int64_t npix, int c, int dtype, void* stream);
+/* The same, fused with the MaxPool2d(2) that consumes the activation in `Down` (unet_parts.py:34; floor mode: an
+ * odd last row/column is not pooled): out = relu(y*scale+shift) [n][h][w], pool = 2x2 max of out [n][h/2][w/2].
+ * Returns UNETK_ERR_SHAPE when c/(16/es) does not divide 256 (use bn_relu_apply + maxpool2x2_fwd then). */
+int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                             void* pool, int ldp, int n, int h, int w, int c, int dtype, void* stream);
 /* backward through ReLU and train-mode BN: reduce (sums [REPLICAS][c][2] doubles, zeroed by the caller) ->
  * finalize (dgamma, dbeta, coef [3][c]) -> apply (dy = coef0*dz - coef1 - coef2*(y-mean)). */
 int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,

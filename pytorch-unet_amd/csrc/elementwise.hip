@@ -163,6 +163,61 @@ __global__ __launch_bounds__(256) void bn_relu_apply_fixed_kernel(const T* __res
   }
 }
 
+// BN + ReLU apply fused with the MaxPool2d(2) that follows it in the encoder (unet_parts.py:20-21 then :34): one
+// thread owns a 2x2 pixel quad x one 16-byte channel piece, writes the four activations (into the concat buffer's
+// skip half) and, for complete quads (floor mode drops an odd last row/column), their maximum -- the pooled tensor
+// costs no read pass of its own.  Fixed-piece layout as above (coefficients in registers).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ out,
+                                                                 int ldo, T* __restrict__ pool, int ldp, int N, int H,
+                                                                 int W, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const int lanes = 256 / ppp;
+  const int c0 = (threadIdx.x % ppp) * E;
+  const int plane = threadIdx.x / ppp;
+  float sc[E], sh[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; }
+  const int QH = (H + 1) / 2, QW = (W + 1) / 2, PH = H / 2, PW = W / 2;
+  const long nquads = (long)N * QH * QW;
+  for (long q = (long)blockIdx.x * lanes + plane; q < nquads; q += (long)gridDim.x * lanes) {
+    const int qx = (int)(q % QW);
+    const long r = q / QW;
+    const int qy = (int)(r % QH);
+    const long n = r / QH;
+    const int y0 = 2 * qy, x0 = 2 * qx;
+    const bool has_x1 = x0 + 1 < W, has_y1 = y0 + 1 < H;
+    const long p00 = (n * H + y0) * W + x0;
+    float v[4][E];
+    Vec<T>::load(y + p00 * ldy + c0, v[0]);
+    if (has_x1) Vec<T>::load(y + (p00 + 1) * ldy + c0, v[1]);
+    if (has_y1) Vec<T>::load(y + (p00 + W) * ldy + c0, v[2]);
+    if (has_x1 && has_y1) Vec<T>::load(y + (p00 + W + 1) * ldy + c0, v[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[k][i] = fmaxf(fmaf(v[k][i], sc[i], sh[i]), 0.f);
+    Vec<T>::store(out + p00 * ldo + c0, v[0]);
+    if (has_x1) Vec<T>::store(out + (p00 + 1) * ldo + c0, v[1]);
+    if (has_y1) Vec<T>::store(out + (p00 + W) * ldo + c0, v[2]);
+    if (has_x1 && has_y1) {
+      Vec<T>::store(out + (p00 + W + 1) * ldo + c0, v[3]);
+      float m[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        // the pooled value is the maximum of the STORED activations (rounded to T), as MaxPool2d sees them
+        const float a = to_f32(from_f32<T>(v[0][i])), b = to_f32(from_f32<T>(v[1][i]));
+        const float c = to_f32(from_f32<T>(v[2][i])), d = to_f32(from_f32<T>(v[3][i]));
+        m[i] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+      }
+      Vec<T>::store(pool + ((n * PH + qy) * PW + qx) * ldp + c0, m);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ BN + ReLU backward
 // pass 1: per-channel  S1 = sum dz,  S2 = sum dz*xhat   with dz = dout * [bn(y) > 0], xhat = (y-mean)*invstd
 template <typename T>
@@ -829,6 +884,22 @@ int unetk_predict_mask(const void* logits, int ld, int n, int h, int w, int n_cl
   DISPATCH_T(dtype, hipLaunchKernelGGL(predict_mask_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)logits, ld, n, h, w, n_classes, out_h, out_w, threshold,
                                        (long long*)mask));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                             void* pool, int ldp, int n, int h, int w, int c, int dtype, void* stream) {
+  if (int e = check_act(y, ldy, c, dtype)) return e;
+  if (int e = check_act(out, ldo, c, dtype)) return e;
+  if (int e = check_act(pool, ldp, c, dtype)) return e;
+  if (!scale || !shift) return UNETK_ERR_ARG;
+  if (n <= 0 || h < 2 || w < 2) return UNETK_ERR_SHAPE;
+  const int ppp = c / (dtype == UNETK_BF16 ? 8 : 4);
+  if (ppp > 256 || 256 % ppp) return UNETK_ERR_SHAPE;   // callers fall back to apply + maxpool2x2_fwd
+  const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_pool_kernel<T>, dim3(ew_grid(nquads, 256 / ppp, 256 * 4)), dim3(256),
+                                       0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (T*)pool,
+                                       ldp, n, h, w, c));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

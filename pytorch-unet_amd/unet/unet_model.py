@@ -37,14 +37,17 @@ class _UNetImpl:
                 out_view = cat[..., :c_out]
             else:
                 cat, out_view = None, None
-            a, s = blocks.double_conv_fwd(dc, cur, dt, out=out_view)
+            pooled = None
+            if k < 4:
+                if hh < 2 or ww < 2:
+                    raise RuntimeError('UNet: input too small for four 2x2 poolings')
+                pooled = ops.new_nhwc(n, hh // 2, ww // 2, c_out, dt, x.device)   # Down's MaxPool2d, fused into BN+ReLU
+            a, s = blocks.double_conv_fwd(dc, cur, dt, out=out_view, pool_out=pooled)
             saved['enc'].append(s)
             if k < 4:
                 skips.append((cat, c_out))
                 saved['pool_in'].append(a)
-                if hh < 2 or ww < 2:
-                    raise RuntimeError('UNet: input too small for four 2x2 poolings')
-                cur = ops.maxpool_fwd(a)
+                cur = pooled
                 hh, ww = hh // 2, ww // 2
             else:
                 cur = a

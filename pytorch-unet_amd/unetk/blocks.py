@@ -57,7 +57,7 @@ def _check_bn(bn):
         raise RuntimeError('BatchNorm parameters must be fp32 (keep the model in fp32 and use autocast for bf16)')
 
 
-def conv_bn_relu_fwd(conv, bn, x, dtype, out=None):
+def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
     """One conv3x3 -> BN -> ReLU.  x: NHWC view (fp32 image for the first layer, else `dtype`).
     Returns (activation, saved) with saved = (x, y, state)."""
     c_in, c_out = conv.in_channels, conv.out_channels
@@ -88,7 +88,7 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None):
         ops.bn_train_finalize(stats, n * h * w, _B, st, float(momentum or 0.0), float(bn.eps))
     else:
         ops.bn_eval_params(bn, st, float(bn.eps))
-    act = ops.bn_relu_apply(y, st, out=out)
+    act = ops.bn_relu_apply(y, st, out=out, pool_out=pool_out)
     return act, (x, y, st)
 
 
@@ -122,10 +122,11 @@ def _grad_buf(grads, p):
 
 
 # ------------------------------------------------------------------------------------ DoubleConv
-def double_conv_fwd(dc, x, dtype, out=None):
+def double_conv_fwd(dc, x, dtype, out=None, pool_out=None):
+    """pool_out: optional [N,H//2,W//2,C] buffer that receives MaxPool2d(2) of the block's output (fused)."""
     seq = dc.double_conv
     a1, s1 = conv_bn_relu_fwd(seq[0], seq[1], x, dtype)
-    a2, s2 = conv_bn_relu_fwd(seq[3], seq[4], a1, dtype, out=out)
+    a2, s2 = conv_bn_relu_fwd(seq[3], seq[4], a1, dtype, out=out, pool_out=pool_out)
     return a2, (s1, s2)
 
 

@@ -236,13 +236,29 @@ def bn_eval_params(bn, state, eps):
                                      stream_ptr()), 'unetk_bn_eval_params')
 
 
-def bn_relu_apply(y, state, out=None):
+def bn_relu_apply(y, state, out=None, pool_out=None):
+    """relu(bn(y)); with pool_out also the MaxPool2d(2) of the result (one fused pass)."""
     n, h, w, c, ldy = nhwc_meta(y, 'bn input')
     if out is None:
         out = new_nhwc(n, h, w, c, y.dtype, y.device)
     _, _, _, _, ldo = nhwc_meta(out, 'bn output')
+    if pool_out is not None:
+        pn, ph, pw, pc, ldp = nhwc_meta(pool_out, 'pool output')
+        if (pn, ph, pw, pc) != (n, h // 2, w // 2, c) or pool_out.dtype != y.dtype:
+            raise RuntimeError('bn_relu_apply: pool_out must be [N, H//2, W//2, C] of the activation dtype')
+        rc = fn['unetk_bn_relu_apply_pool'](y.data_ptr(), ldy, state.scale.data_ptr(), state.shift.data_ptr(),
+                                            out.data_ptr(), ldo, pool_out.data_ptr(), ldp, n, h, w, c,
+                                            dtype_code(y.dtype), stream_ptr())
+        if rc == 0:
+            return out
+        if rc != -1:                      # -1: channel count the fused kernel does not take -> two passes below
+            check(rc, 'unetk_bn_relu_apply_pool')
     check(fn['unetk_bn_relu_apply'](y.data_ptr(), ldy, state.scale.data_ptr(), state.shift.data_ptr(), out.data_ptr(),
                                     ldo, n * h * w, c, dtype_code(y.dtype), stream_ptr()), 'unetk_bn_relu_apply')
+    if pool_out is not None:
+        _, _, _, _, ldp = nhwc_meta(pool_out, 'pool output')
+        check(fn['unetk_maxpool2x2_fwd'](out.data_ptr(), ldo, pool_out.data_ptr(), ldp, n, h, w, c, dtype_code(y.dtype),
+                                         stream_ptr()), 'unetk_maxpool2x2_fwd')
     return out
 
 

@@ -349,3 +349,22 @@ def test_clip_rmsprop_matches_torch(momentum, weight_decay, max_norm):
         assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
         assert rel_err(gd.cpu().numpy(), ref_p.grad.numpy()) < 1e-5            # clipped gradient written back
         assert rel_err(p.cpu().numpy(), ref_p.detach().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,h,w,c', [(2, 9, 13, 64), (1, 16, 22, 128), (1, 7, 2, 64)])
+def test_bn_relu_apply_pool_equals_apply_then_pool(dtype, n, h, w, c):
+    """The fused BN+ReLU+MaxPool2d(2) pass is bit-identical to the two separate passes, writes into a channel slice,
+    and leaves the dropped odd row/column un-pooled."""
+    from unetk import ops
+    y = _rand((n, h, w, c), 31).to(dtype).cuda()
+    st = ops.BNState(c, 'cuda')
+    st.scale.copy_(_rand((c,), 32) + 0.2)
+    st.shift.copy_(_rand((c,), 33) * 0.3)
+    ref = ops.bn_relu_apply(y, st)
+    ref_pool = ops.maxpool_fwd(ref)
+    cat = torch.full((n, h, w, 2 * c), 7.0, dtype=dtype, device='cuda')
+    pool = torch.empty((n, h // 2, w // 2, c), dtype=dtype, device='cuda')
+    out = ops.bn_relu_apply(y, st, out=cat[..., :c], pool_out=pool)
+    assert torch.equal(out, ref) and torch.equal(pool, ref_pool)
+    assert torch.equal(cat[..., c:], torch.full_like(cat[..., c:], 7.0))
