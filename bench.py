@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch-size', '-b', type=int, default=16, help='images per GPU (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=H, help='sanity runs of other BASELINE configs; the metric is quoted at 640')
+    ap.add_argument('--width', type=int, default=W)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -97,8 +99,9 @@ def main():
     trainer = Trainer(net, amp=True)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch_size
-    images = torch.rand((B, 3, H, W), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
-    masks = (torch.rand((B, H, W), device=dev, generator=g) < 0.2).long()
+    hh, ww = args.height, args.width
+    images = torch.rand((B, 3, hh, ww), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    masks = (torch.rand((B, hh, ww), device=dev, generator=g) < 0.2).long()
 
     for _ in range(args.warmup):
         trainer.step(images, masks)
@@ -158,14 +161,15 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / elapsed
         out = {
-            'metric': 'train images/sec @959x640 bf16', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
+            'metric': f'train images/sec @{ww}x{hh} bf16', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'UNet(3,2,bilinear=False) Carvana scale=0.5 (959x640) bf16 training step, '
-                                   f'batch {B} per GPU (BASELINE.json configs[1])',
+                                   f'batch {B} per GPU (BASELINE.json configs[1])' if (hh, ww) == (H, W) else
+                                   f'UNet(3,2,bilinear=False) {ww}x{hh} bf16 training step, batch {B} per GPU (sanity run)',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'optimizer': 'RMSprop+clip_grad_norm',
                        'loss': 'CE+dice'},
-            'model_tflops': ips * TRAIN_GFLOP_PER_IMG / 1e3, 'final_loss': loss_val,
+            'model_tflops': ips * TRAIN_GFLOP_PER_IMG * (hh * ww) / (H * W) / 1e3, 'final_loss': loss_val,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(out), flush=True)
