@@ -332,20 +332,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams P) {
 // after the barrier) and relied on a second resident workgroup to cover it.
 __device__ uint4 g_zero_page_conv[8];
 
-template <typename T, int NB, int KS, int NW, int MB>
+// KI >= KS: k-steps of input per LDS input buffer.  With KI = 2 KS the input tile holds 64 B per pixel and is refilled
+// every second weight chunk: every 128-byte line of the activation is then fetched from L2 twice per tile instead
+// of four times (a 16-channel chunk uses 32 B of each pixel's line; TCC_REQ showed 25 M of the 37 M requests of a
+// 512->512 launch were such quarter-used lines, and the fill path is what the MFMA phase waits for).
+template <typename T, int NB, int KS, int NW, int MB, int KI>
 __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   constexpr int E = ElemTraits<T>::E;
-  constexpr int NP = 2 * KS, CH = NP * E, S = 32 * KS, PPR = 256 / S, TAPS = 9;
+  static_assert(KI % KS == 0, "input buffer = whole number of weight chunks");
+  constexpr int R = KI / KS;                       // weight chunks per input chunk
+  constexpr int NP = 2 * KI, CHI = NP * E, CH = 2 * KS * E, S = 32 * KI, PPR = 256 / S, TAPS = 9;
   constexpr int HP = 34;                          // halo row pitch (pixels)
   constexpr int TR = MB * NW;                     // tile rows: each wave owns MB
   constexpr int NPIX = (TR + 2) * HP;
   constexpr int IN_INSTR = (NPIX * NP + 63) / 64; // 39 one-KiB DMA pieces
   constexpr int IN_BYTES = IN_INSTR * 1024;
   constexpr int WFRAGS = TAPS * KS * NB;
-  constexpr int BUF = IN_BYTES + WFRAGS * 1024;
+  constexpr int W_BYTES = WFRAGS * 1024;
   constexpr int BN = 32 * NB;
   constexpr int IN_PER_WAVE = (IN_INSTR + NW - 1) / NW;
+  constexpr int IN_PER_SUB = (IN_PER_WAVE + R - 1) / R;    // input pieces a wave issues per weight chunk
   constexpr int W_PER_WAVE = (WFRAGS + NW - 1) / NW;
+  // LDS: [input 0][input 1][weights 0][weights 1]
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -359,7 +367,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
   if (tile_begin >= tile_end) return;
 
-  const int nchunks = P.Cin / CH;
+  const int nchunks = P.Cin / CH;               // weight chunks
+  const int nin = P.Cin / CHI;                  // input chunks
   const char* wbase = reinterpret_cast<const char*>(P.wpk) + (size_t)nt * nchunks * (WFRAGS * 1024);
   const char* zero = reinterpret_cast<const char*>(g_zero_page_conv);
 
@@ -397,23 +406,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   // one 1-KiB DMA piece: q < IN_PER_WAVE -> input piece q, else weight fragment q - IN_PER_WAVE.  Branch-free
   // (a branch inside the MFMA loop ends the basic block and costs a full lgkmcnt(0) wait): surplus slots repeat the
   // last piece (same bytes to the same place), `live` = false sends every source to the zero page.
-  constexpr int NDMA = IN_PER_WAVE + W_PER_WAVE;
-  auto issue_piece = [&](int q, int chunk, unsigned buf, bool live) {
-    if (q < IN_PER_WAVE) {
-      const int fi = min(q * NW + wid, IN_INSTR - 1);
-      const char* src = (live && dma_off[q] >= 0) ? ximg + dma_off[q] + (long)chunk * CH * sizeof(T) : zero;
-      // (the nontemporal form of this DMA was 15 % slower: halo rows and n-tiles re-read these lines from L2)
-      glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
-    } else {
-      const int fi = min((q - IN_PER_WAVE) * NW + wid, WFRAGS - 1);
-      const char* src = live ? wbase + (size_t)chunk * (WFRAGS * 1024) + lane * 16 + fi * 1024 : zero;
-      glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + IN_BYTES + fi * 1024));
-    }
+  auto issue_input = [&](int q, int in_chunk, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, IN_INSTR - 1);
+    const char* src = (live && dma_off[q] >= 0) ? ximg + dma_off[q] + (long)in_chunk * CHI * sizeof(T) : zero;
+    // (the nontemporal form of this DMA was 15 % slower: halo rows and n-tiles re-read these lines from L2)
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
-  auto issue_dma = [&](int chunk, unsigned buf) {
-#pragma unroll
-    for (int q = 0; q < NDMA; ++q) issue_piece(q, chunk, buf, true);
+  auto issue_weight = [&](int q, int chunk, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, WFRAGS - 1);
+    const char* src = live ? wbase + (size_t)chunk * W_BYTES + lane * 16 + fi * 1024 : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
+  constexpr int NDMA = IN_PER_SUB + W_PER_WAVE;     // pieces per wave per weight chunk
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -427,9 +431,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
 
   setup_stage(tile_begin);
   const unsigned lds0 = lds_address(smem);
-  issue_dma(0, lds0);
+  const unsigned ldsw0 = lds0 + 2 * IN_BYTES;
+#pragma unroll
+  for (int q = 0; q < IN_PER_WAVE; ++q) issue_input(q, 0, lds0, true);
+#pragma unroll
+  for (int q = 0; q < W_PER_WAVE; ++q) issue_weight(q, 0, ldsw0, true);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  int cur = 0;
+  int curi = 0, curw = 0;
   // BN statistics of all tiles of this workgroup: per tile in fp32 (as the values are produced), across tiles in
   // fp32 for bf16 tensors and in fp64 for fp32 tensors (their 1e-4 parity bar needs E[x^2] - mean^2 to keep its bits)
   using StatAcc = typename std::conditional<sizeof(T) == 4, double, float>::type;
@@ -438,52 +446,73 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   for (int nb = 0; nb < NB; ++nb) tsum[nb] = tsq[nb] = 0;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
-    for (int kc = 0; kc < nchunks; ++kc) {
-      char* lds_in = smem + cur * BUF;
-      char* lds_w = lds_in + IN_BYTES;
-      // DMA of the next chunk (of this tile or the first of the next tile) into the other buffer, ONE piece per
-      // k-step between the MFMAs: an LDS-DMA instruction holds the issuing wave for 60-185 cycles
-      // (MI355X_MICROARCH "LDS-DMA piece issue cost"); issued in a burst at the top of the iteration all eight waves
-      // stall together and the matrix pipe drains, spread out the partner wave on the SIMD keeps it fed.
-      int next_chunk = 0;
-      bool live = !(P.dbg & 1);
-      if (kc + 1 < nchunks) {
-        next_chunk = kc + 1;
-      } else if (tile + 1 < tile_end) {
-        setup_stage(tile + 1);
-      } else {
-        live = false;
+    for (int ic = 0; ic < nin; ++ic) {
+      // the NEXT input chunk (of this tile, or the first of the next tile) is staged while this one is consumed
+      int next_in = ic + 1;
+      bool live_in = !(P.dbg & 1);
+      if (ic + 1 == nin) {
+        next_in = 0;
+        if (tile + 1 < tile_end) setup_stage(tile + 1);
+        else live_in = false;
       }
-      const unsigned nbuf = lds0 + (cur ^ 1) * BUF;
-      constexpr int NSTEP = TAPS * KS;
-      constexpr int PPS = (NDMA + NSTEP - 1) / NSTEP;     // DMA pieces per k-step (1 with 8 waves, 2 with 4)
-      uint4 fa[2][MB], fb[2][NB];
-      auto load_frags = [&](int step, uint4 (&a)[MB], uint4 (&b)[NB]) {
-        const int t = step / KS, ks = step % KS;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb][t] ^ (ks << 5)));
+      for (int sub = 0; sub < R; ++sub) {
+        const int kc = ic * R + sub;
+        const char* lds_in = smem + curi * IN_BYTES;
+        const char* lds_w = smem + 2 * IN_BYTES + curw * W_BYTES;
+        // DMA of the next weight chunk and of 1/R of the next input chunk, ONE piece per k-step between the MFMAs:
+        // an LDS-DMA instruction holds the issuing wave for 60-185 cycles (MI355X_MICROARCH "LDS-DMA piece issue
+        // cost"); in a burst all eight waves stall together and the matrix pipe drains, spread out the partner wave
+        // on the SIMD keeps it fed.
+        int next_w = kc + 1;
+        bool live_w = !(P.dbg & 1);
+        if (kc + 1 == nchunks) {
+          next_w = 0;
+          live_w = live_w && (tile + 1 < tile_end);
+        }
+        const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
+        const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
+        constexpr int NSTEP = TAPS * KS;
+        constexpr int PPS = (NDMA + NSTEP - 1) / NSTEP;     // DMA pieces per k-step (1 with 8 waves)
+        auto issue_piece = [&](int q) {
+          if (q < IN_PER_SUB) {
+            const int qi = sub * IN_PER_SUB + q;
+            if (qi < IN_PER_WAVE) issue_input(qi, next_in, nbuf_in, live_in);
+          } else {
+            issue_weight(q - IN_PER_SUB, next_w, nbuf_w, live_w);
+          }
+        };
+        uint4 fa[2][MB], fb[2][NB];
+        auto load_frags = [&](int step, uint4 (&a)[MB], uint4 (&b)[NB]) {
+          const int t = step / KS, ks = step % KS;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          b[nb] = *reinterpret_cast<const uint4*>(lds_w + (step * NB + nb) * 1024 + lane * 16);
-      };
-      if (!(P.dbg & 2)) {
-      load_frags(0, fa[0], fb[0]);
+          for (int mb = 0; mb < MB; ++mb)
+            a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb][t] ^ ((sub * KS + ks) << 5)));
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
-        if (st + 1 < NSTEP) load_frags(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
+          for (int nb = 0; nb < NB; ++nb)
+            b[nb] = *reinterpret_cast<const uint4*>(lds_w + (step * NB + nb) * 1024 + lane * 16);
+        };
+        if (!(P.dbg & 2)) {
+          load_frags(0, fa[0], fb[0]);
 #pragma unroll
-        for (int q = st * PPS; q < (st + 1) * PPS && q < NDMA; ++q) issue_piece(q, next_chunk, nbuf, live);
+          for (int st = 0; st < NSTEP; ++st) {
+            if (st + 1 < NSTEP) load_frags(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int q = st * PPS; q < (st + 1) * PPS && q < NDMA; ++q) issue_piece(q);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[st & 1][mb], fb[st & 1][nb]);
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[st & 1][mb], fb[st & 1][nb]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NDMA; ++q) issue_piece(q);
+        }
+        // next chunks landed (this wave's DMAs) and every wave is done reading the current buffers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        curw ^= 1;
       }
-      } else if (live) {
-        issue_dma(next_chunk, nbuf);
-      }
-      // next chunk landed (this wave's DMAs) and every wave is done reading the current buffer
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      cur ^= 1;
+      curi ^= 1;
     }
 
     // ---- epilogue of this tile.  64-bit address arithmetic only per row block (wave-uniform); an element adds a
@@ -548,9 +577,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   }
 }
 
-template <typename T, int NB, int KS, int NW, int MB = 2> int launch_db(const ConvParams& P, hipStream_t s) {
-  constexpr size_t lds = 2 * ((size_t)(((MB * NW + 2) * 34 * 2 * KS + 63) / 64) * 1024 + 9 * KS * NB * 1024);
-  UNETK_ALLOW_LDS((conv3x3_db_kernel<T, NB, KS, NW, MB>), lds);
+template <typename T, int NB, int KS, int NW, int MB = 2, int KI = KS> int launch_db(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * ((size_t)(((MB * NW + 2) * 34 * 2 * KI + 63) / 64) * 1024 + 9 * KS * NB * 1024);
+  UNETK_ALLOW_LDS((conv3x3_db_kernel<T, NB, KS, NW, MB, KI>), lds);
   ConvParams Q = P;
   Q.tiles_y = host_cdiv(P.H, MB * NW);
   const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
@@ -566,7 +595,7 @@ template <typename T, int NB, int KS, int NW, int MB = 2> int launch_db(const Co
   Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW, MB>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
+  hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW, MB, KI>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -835,6 +864,9 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     const Conv3Config cfg = conv3_config(P.Cout);
     if (gen == 2 || cfg.NB == 4) {
       if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+      static const int ki = getenv("UNETK_CONV_KI") ? atoi(getenv("UNETK_CONV_KI")) : 2;   // 1: A/B against 32-B input rows
+      if (cfg.NB == 4 && ki == 2)
+        return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
       if (cfg.NB == 4) return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8>(P, s) : launch_db<float, 4, 1, 8>(P, s);
       // 64-channel-wide outputs (measured: two 4-wave workgroups per CU with 32-byte chunks were 10 % slower)
       if (cfg.KS == 1)    // perf A/B (UNETK_CONV_KS64=1): 32 x 32-pixel tiles, 4 row blocks per wave (0.75 KiB LDS / MFMA)

@@ -10,7 +10,7 @@ layers = [(640, 959, 64, 64), (640, 959, 128, 64), (320, 479, 64, 128), (320, 47
           (80, 119, 1024, 512), (40, 59, 512, 1024), (40, 59, 1024, 1024)]
 dt = torch.bfloat16
 if os.environ.get('ONLY'):
-    layers = [layers[int(os.environ['ONLY'])]]
+    layers = [layers[int(i)] for i in os.environ['ONLY'].split(',')]
 tot = 0.0
 for (h, w, cin, cout) in layers:
     x = (torch.rand((N, h, w, cin), device='cuda') - 0.5).to(dt)
