@@ -392,6 +392,157 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(Wgrad3Params P) {
   }
 }
 
+// ================================================================================================================
+// conv3x3 wgrad for c_out % 128 == 0: the same column-K pipeline on a 64 (ci) x 128 (co) channel tile.
+//
+// The MFMA phase of wgrad3 needs 77 KiB of LDS-DMA per 2.4 us tile = 32.6 GB/s per CU, and the L2 -> LDS fill path
+// delivers ~35 GB/s per CU (DMA-only ablation): the kernel is fill-bound (feeding the dy tile from the zero page
+// alone lifts it from 1146 to 1513 TFLOP/s).  A 64 x 128 channel tile over 16 x 8 pixels does the same 72 MFMAs per
+// wave and tile with 55 KiB of operands (343 instead of 245 FLOP per staged byte):
+//   LDS per buffer: x halo 18 x 11(pitch) pixels x 128 B + dy 16 x 8 pixels x 256 B = 57 KiB, two buffers
+//   8 waves = 2 (ci halves) x 4 (co quarters), every wave walks all 10 column steps -> no cross-group sum
+//   dy rows are 256 B: the 64-byte group of a wave is XORed with (row & 3), so the four pixel rows of a transposed
+//   read hit four different bank groups whatever the pitch
+constexpr int W4_AP = 11;
+constexpr int W4_A_PIECES = (18 * W4_AP + 7) / 8;     // 25
+constexpr int W4_B_PIECES = 16 * 8 * 256 / 1024;      // 32
+constexpr int W4_PIECES = W4_A_PIECES + W4_B_PIECES;  // 57
+constexpr int W4_BUF = W4_PIECES * 1024;
+constexpr int W4_STEPS = 10;
+constexpr int W4_SLOTS = (W4_PIECES + 7) / 8;         // DMA pieces per wave and tile (8)
+
+__global__ __launch_bounds__(512) void wgrad4_bf16_kernel(Wgrad3Params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 2, wj = wid & 3;
+
+  const int npairs = P.row_tiles * P.col_tiles;
+  int lin = blockIdx.x;                           // XCD-major, see wgrad3
+  if ((gridDim.x & 7) == 0) lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int pair = lin % npairs, split = lin / npairs;
+  const int r0 = (pair / P.col_tiles) * 64, c0 = (pair % P.col_tiles) * 128;
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+  const int sub = (pp & 1) * 8;
+  int addrA[3][2], addrB[2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int k = 8 * (g >> 1) + 4 * rd + q4;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int row = kh + k;
+      const int piece = wi * 4 + 2 * (g & 1) + (pp >> 1);
+      addrA[kh][rd] = (row * W4_AP) * 128 + ((piece ^ swz3(row)) << 4) + sub;
+    }
+    const int pieceb = wj * 4 + 2 * (g & 1) + (pp >> 1);
+    addrB[rd] = W4_A_PIECES * 1024 + (k * 8) * 256 + ((pieceb ^ ((k & 3) << 2)) << 4) + sub;
+  }
+
+  // DMA descriptors: bits 0-7 row+1 rel. to the tile, 8-15 col+1, 16-20 sixteen-byte piece, 24 valid
+  int desc[W4_SLOTS];
+#pragma unroll
+  for (int q = 0; q < W4_SLOTS; ++q) {
+    const int fi = min(q * 8 + wid, W4_PIECES - 1);
+    int d = 0;
+    if (fi < W4_A_PIECES) {
+      const int p = fi * 8 + (lane >> 3), ls = lane & 7;
+      const int hr = p / W4_AP, hc = p - hr * W4_AP;
+      if (hc < 10 && hr < 18) d = hr | (hc << 8) | ((ls ^ swz3(hr)) << 16) | (1 << 24);
+    } else {
+      const int p = (fi - W4_A_PIECES) * 4 + (lane >> 4), ls = lane & 15;
+      const int hr = p >> 3, hc = p & 7;
+      d = (hr + 1) | ((hc + 1) << 8) | ((ls ^ ((hr & 3) << 2)) << 16) | (1 << 24);
+    }
+    desc[q] = d;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const unsigned lds0 = lds_address(smem);
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const char* sa = nullptr;
+  const char* sb = nullptr;
+  int sy0 = 0, sx0 = 0;
+  auto stage_tile = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    sy0 = (rem / P.tiles_x) * 16;
+    sx0 = (rem % P.tiles_x) * 8;
+    sa = reinterpret_cast<const char*>(P.a + (size_t)img * P.H * P.W * P.lda + r0);
+    sb = reinterpret_cast<const char*>(P.b + (size_t)img * P.H * P.W * P.ldb + c0);
+  };
+  auto issue_piece = [&](int q, unsigned buf, bool live) {     // branch-free, see wgrad3
+    const int fi = min(q * 8 + wid, W4_PIECES - 1);
+    const bool is_a = fi < W4_A_PIECES;
+    const int d = desc[q];
+    const int yy = sy0 + (d & 255) - 1, xx = sx0 + ((d >> 8) & 255) - 1;
+    const int ld = is_a ? P.lda : P.ldb;
+    const char* base = is_a ? sa : sb;
+    const bool ok = live & ((d >> 24) != 0) & ((unsigned)yy < (unsigned)P.H) & ((unsigned)xx < (unsigned)P.W) &
+                    !(P.dbg & 16);
+    const unsigned off = ((unsigned)(yy * P.W + xx) * (unsigned)ld + ((d >> 16) & 31) * 8u) * 2u;
+    const char* src = ok ? base + off : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+
+  if (t_begin < t_end) {
+    stage_tile(t_begin);
+#pragma unroll
+    for (int q = 0; q < W4_SLOTS; ++q) issue_piece(q, lds0, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const char* buf = smem + cur * W4_BUF;
+    const unsigned nbuf = lds0 + (cur ^ 1) * W4_BUF;
+    const bool next = tile + 1 < t_end && !(P.dbg & 1);
+    stage_tile(next ? tile + 1 : tile);
+
+    bf16x8 fa[2][3], fb[4];
+    auto load_step = [&](int cc) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+        fa[cc & 1][kh] = tr_read8(buf + addrA[kh][0] + cc * 128, buf + addrA[kh][1] + cc * 128);
+      if (cc < 8) fb[cc & 3] = tr_read8(buf + addrB[0] + cc * 256, buf + addrB[1] + cc * 256);
+    };
+    load_step(0);
+#pragma unroll
+    for (int cc = 0; cc < W4_STEPS; ++cc) {
+      if (cc + 1 < W4_STEPS) load_step(cc + 1);
+      if (cc < W4_SLOTS) issue_piece(cc, nbuf, next);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int bl = cc - kw;
+        if (bl >= 0 && bl < 8) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cc & 1][kh], fb[bl & 3], acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    cur ^= 1;
+  }
+
+  const int j = lane & 31, h = lane >> 5;
+  float* out = P.slab + (size_t)split * 9 * P.Ca * P.Cb;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + wi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      out[((size_t)t * P.Ca + row) * P.Cb + c0 + wj * 32 + j] = acc[t][i];
+    }
+}
+
 int pick_nsplit3(int ntiles, int npairs) {
   int ns = 256 / npairs;
   if (ns < 1) ns = 1;
@@ -617,6 +768,10 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
   if (kind == 0) {   // bf16 conv3x3: 16x16-pixel tiles
     const int64_t s3 = pick_nsplit3(n * host_cdiv(h, 16) * host_cdiv(w, 16), npairs);
     if (s3 > slabs) slabs = s3;
+    if (c_out % 128 == 0) {   // 64 x 128 channel tiles over 16 x 8 pixels
+      const int64_t s4 = pick_nsplit3(n * host_cdiv(h, 16) * host_cdiv(w, 8), (c_in / 64) * (c_out / 128));
+      if (s4 > slabs) slabs = s4;
+    }
   }
   return slabs * taps * c_in * c_out * 4;
 }
@@ -649,6 +804,24 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     return UNETK_OK;
   }
   if ((int64_t)h * w * (ldx > lddy ? ldx : lddy) * 2 >= (int64_t)1 << 32) return UNETK_ERR_SHAPE;   // 32-bit DMA offsets
+  static const int wide = getenv("UNETK_WGRAD_WIDE") ? atoi(getenv("UNETK_WGRAD_WIDE")) : 1;   // 0: A/B against 64x64 tiles
+  if (c_out % 128 == 0 && wide) {
+    Wgrad3Params P{};
+    P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
+    P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+    P.tiles_x = host_cdiv(w, 8); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
+    P.row_tiles = c_in / 64; P.col_tiles = c_out / 128;
+    P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
+    P.dbg = getenv("UNETK_WGRAD_DBG") ? atoi(getenv("UNETK_WGRAD_DBG")) : 0;
+    const size_t lds = 2 * W4_BUF;
+    UNETK_ALLOW_LDS((wgrad4_bf16_kernel), lds);
+    hipLaunchKernelGGL(wgrad4_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                       (hipStream_t)stream, P);
+    UNETK_CHECK_LAUNCH();
+    launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   Wgrad3Params P{};
   P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
   P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
