@@ -52,9 +52,98 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
   }
 }
 
+// ---- all weights of a network in ONE launch: a plan (array of PlanItem, built on the host, kept on the device by
+// the caller) lists every (parameter, packed buffer, geometry); the kernel finds its item by the running piece count
+struct PlanItem {
+  const float* src;
+  void* dst;
+  long long piece_begin;     // first 16-byte piece of this item in the concatenated index space
+  int kind, c_out, c_in, dtype;
+  int N, K, taps, KS, outer, NB;
+  int pad_[2];
+};
+static_assert(sizeof(PlanItem) % 8 == 0, "plain layout");
+
+template <typename T>
+__device__ __forceinline__ void pack_piece(const PlanItem& it, long idx) {
+  constexpr int E = ElemTraits<T>::E;
+  const int CH = 2 * it.KS * E;
+  const int nchunks = it.K / CH;
+  const int lane = (int)(idx & 63);
+  long f = idx >> 6;
+  const int nb = (int)(f % it.NB); f /= it.NB;
+  const int ks = (int)(f % it.KS); f /= it.KS;
+  const int tap_in = (int)(f % it.taps); f /= it.taps;
+  const int kc = (int)(f % nchunks); f /= nchunks;
+  const int tap_out = (int)(f % it.outer); f /= it.outer;
+  const int nt = (int)f;
+  const int tap = it.outer > 1 ? tap_out : tap_in;
+  const int j = lane & 31, h = lane >> 5;
+  const int o = nt * 32 * it.NB + it.NB * j + nb;
+  T out[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = kc * CH + ks * 2 * E + h * E + e;
+    long s;
+    if (it.kind == 0) s = ((long)o * it.c_in + i) * 9 + tap;
+    else if (it.kind == 1) s = ((long)i * it.c_in + o) * 9 + (8 - tap);
+    else if (it.kind == 2) { const int ab = o / it.c_out, co = o - ab * it.c_out; s = ((long)i * it.c_out + co) * 4 + ab; }
+    else s = ((long)o * it.c_out + i) * 4 + tap;
+    out[e] = from_f32<T>(it.src[s]);
+  }
+  *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + idx * E) = *reinterpret_cast<const uint4*>(out);
+}
+
+__global__ __launch_bounds__(256) void pack_plan_kernel(const PlanItem* __restrict__ plan, int n_items, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int lo = 0, hi = n_items - 1;          // last item whose piece_begin <= idx
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (plan[mid].piece_begin <= idx) lo = mid; else hi = mid - 1;
+    }
+    const PlanItem it = plan[lo];
+    if (it.dtype == UNETK_BF16) pack_piece<bf16>(it, idx - it.piece_begin);
+    else pack_piece<float>(it, idx - it.piece_begin);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t unetk_pack_plan_bytes(int n_items) { return n_items > 0 ? (int64_t)n_items * sizeof(PlanItem) : UNETK_ERR_ARG; }
+
+int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* plan_host, int64_t plan_bytes) {
+  if (!items || !plan_host || n_items <= 0 || plan_bytes < unetk_pack_plan_bytes(n_items)) return UNETK_ERR_ARG;
+  PlanItem* plan = static_cast<PlanItem*>(plan_host);
+  long long total = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const unetk_pack_item& u = items[i];
+    const int64_t bytes = unetk_packed_weight_bytes(u.kind, u.c_out, u.c_in, u.dtype);
+    if (bytes < 0) return bytes;
+    if (!u.src || !u.dst) return UNETK_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(u.dst) & 15) return UNETK_ERR_ALIGN;
+    PackGeo g;
+    pack_geo(u.kind, u.c_out, u.c_in, &g);
+    PlanItem p{};
+    p.src = u.src; p.dst = u.dst; p.piece_begin = total;
+    p.kind = u.kind; p.c_out = u.c_out; p.c_in = u.c_in; p.dtype = u.dtype;
+    p.N = g.N; p.K = g.K; p.taps = g.taps; p.KS = g.KS; p.outer = g.outer; p.NB = g.NB;
+    plan[i] = p;
+    total += bytes / 16;
+  }
+  return total;
+}
+
+int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_pieces, void* stream) {
+  if (!plan_dev || n_items <= 0 || total_pieces <= 0) return UNETK_ERR_ARG;
+  long g = (total_pieces + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_plan_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const PlanItem*>(plan_dev), n_items, (long)total_pieces);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
 
 int unetk_version(void) { return 1; }
 const char* unetk_arch(void) { return "gfx950"; }

@@ -17,6 +17,7 @@ from .unet_parts import DoubleConv, Down, Up, OutConv
 class _UNetImpl:
     def __init__(self, net, dtype):
         self.net, self.dtype = net, dtype
+        self.will_backward = False
 
     # ---- forward
     def fwd(self, x):
@@ -26,6 +27,9 @@ class _UNetImpl:
         ups = [net.up1, net.up2, net.up3, net.up4]
         enc = [net.inc] + [d.maxpool_conv[1] for d in downs]
         saved = {'enc': [], 'pool_in': [], 'up': [], 'dec': [], 'cats': []}
+        blocks.pack_all(net, dt, self.will_backward)         # one launch re-packs every conv weight that changed
+        bn_channels = sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d))
+        ops.begin_stats_arena(x.device, bn_channels)       # one memset for all BatchNorm statistics of this pass
         # encoder: level k's output is written straight into the first half of that level's concat buffer
         cur, hh, ww = x, h, w
         skips = []
@@ -72,6 +76,8 @@ class _UNetImpl:
         init = getattr(net, '_initial_grads', None)
         if init is not None:
             grads.update(init())          # gradients land in one flat, bucket-ordered buffer (unetk.ddp)
+        ops.begin_stats_arena(dlogits.device,
+                              sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)))
 
         def done(params):
             if ready is not None:
@@ -137,6 +143,7 @@ class UNet(nn.Module):
         impl = _UNetImpl(self, blocks.activation_dtype(x))
         params = self.hot_path_params()
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            impl.will_backward = True          # also pack the dgrad weight streams in the forward's single launch
             return BlockFn.apply(impl, 1, x, *params)
         out, _ = impl.fwd(ops.to_nhwc(x))
         return ops.to_nchw(out)

@@ -41,6 +41,68 @@ def packed_weight(mod, kind, dtype, c_out, c_in):
     return t
 
 
+def pack_all(net, dtype, need_dgrad):
+    """Refresh the packed weights of EVERY MFMA convolution of `net` in one launch (unetk_pack_plan_*), then let
+    packed_weight() hit its cache: 42 per-layer pack launches per training step become one.  The plan (device copy
+    of the per-layer records) is cached on the net and rebuilt when a parameter or packed buffer moved; layers whose
+    weights are not plain contiguous fp32 keep the per-layer path."""
+    import ctypes
+    import numpy as np
+    import torch.nn as nn
+    targets = []
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.in_channels > 4:
+            kinds, c_out, c_in = (0, 1), m.out_channels, m.in_channels
+        elif isinstance(m, nn.ConvTranspose2d):
+            kinds, c_out, c_in = (2, 3), m.out_channels, m.in_channels
+        else:
+            continue
+        w = m.weight
+        if w.dtype != torch.float32 or not w.is_contiguous() or not w.is_cuda:
+            continue
+        for kind in kinds if need_dgrad else kinds[:1]:
+            targets.append((m, kind, c_out, c_in))
+    if not targets:
+        return
+
+    def stale(t):
+        m, kind = t[0], t[1]
+        hit = m.__dict__.get('_unetk_pack', {}).get((kind, dtype))
+        return hit is None or hit[0] != m.weight._version or hit[1] != m.weight.data_ptr()
+    if not any(stale(t) for t in targets):
+        return
+    dc = ops.dtype_code(dtype)
+    plans = net.__dict__.setdefault('_unetk_pack_plans', {})
+    plan = plans.get((dtype, need_dgrad))
+    srcs = tuple(t[0].weight.data_ptr() for t in targets)
+    if plan is None or plan['srcs'] != srcs:
+        es = torch.empty(0, dtype=dtype).element_size()
+        bufs = []
+        for m, kind, c_out, c_in in targets:
+            nbytes = ops.fn['unetk_packed_weight_bytes'](kind, c_out, c_in, dc)
+            if nbytes < 0:
+                ops.check(int(nbytes), 'unetk_packed_weight_bytes')
+            bufs.append(torch.empty(nbytes // es, dtype=dtype, device=m.weight.device))
+
+        class Item(ctypes.Structure):
+            _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('kind', ctypes.c_int),
+                        ('c_out', ctypes.c_int), ('c_in', ctypes.c_int), ('dtype', ctypes.c_int)]
+        items = (Item * len(targets))(*[Item(t[0].weight.data_ptr(), b.data_ptr(), t[1], t[2], t[3], dc)
+                                        for t, b in zip(targets, bufs)])
+        nbytes = int(ops.fn['unetk_pack_plan_bytes'](len(targets)))
+        host = np.zeros(nbytes, dtype=np.uint8)
+        total = int(ops.fn['unetk_pack_plan_build'](ctypes.addressof(items), len(targets), host.ctypes.data, nbytes))
+        if total <= 0:
+            ops.check(total, 'unetk_pack_plan_build')
+        plan = {'srcs': srcs, 'bufs': bufs, 'dev': torch.from_numpy(host).to(targets[0][0].weight.device),
+                'total': total, 'n': len(targets)}
+        plans[(dtype, need_dgrad)] = plan
+    ops.check(ops.fn['unetk_pack_plan_run'](plan['dev'].data_ptr(), plan['n'], plan['total'], ops.stream_ptr()),
+              'unetk_pack_plan_run')
+    for (m, kind, _, _), buf in zip(targets, plan['bufs']):
+        m.__dict__.setdefault('_unetk_pack', {})[(kind, dtype)] = (m.weight._version, m.weight.data_ptr(), buf)
+
+
 def _f32c(p):
     t = p.detach()
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()

@@ -67,7 +67,42 @@ def pack_weight(kind, w_param, c_out, c_in, dtype):
 
 
 # ------------------------------------------------------------------------------------ conv 3x3
+class ZeroArena:
+    """One zero-filled fp64 buffer handed out in slices: the 18 BatchNorm layers of a pass each need a zeroed
+    [replicas][C][2] accumulator, and 18 tiny fill kernels cost more than one memset of the lot.  `begin()` re-zeroes
+    the buffer (one launch); every slice is consumed (reduced + finalised) before the next `begin()` on that stream."""
+
+    def __init__(self):
+        self.buf, self.used = None, 0
+
+    def begin(self, device, n_doubles):
+        if self.buf is None or self.buf.numel() < n_doubles or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(n_doubles, dtype=torch.float64, device=device)
+        else:
+            self.buf.zero_()
+        self.used = 0
+
+    def take(self, n_doubles, device):
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n_doubles > self.buf.numel():
+            return None
+        t = self.buf[self.used:self.used + n_doubles]
+        self.used += n_doubles
+        return t
+
+
+_ARENA = ZeroArena()
+
+
+def begin_stats_arena(device, total_channels):
+    """Zero, in one launch, accumulators for BatchNorm layers with `total_channels` channels in all (whole-net
+    forward and backward passes call this once each)."""
+    _ARENA.begin(device, nat.STAT_REPLICAS * 2 * int(total_channels))
+
+
 def new_stats(c, device):
+    t = _ARENA.take(nat.STAT_REPLICAS * c * 2, device)
+    if t is not None:
+        return t.view(nat.STAT_REPLICAS, c, 2)
     return torch.zeros((nat.STAT_REPLICAS, c, 2), dtype=torch.float64, device=device)
 
 
