@@ -406,3 +406,31 @@ def test_preprocess_mask_and_errors():
     assert (out == 1).all()
     with pytest.raises(AssertionError):
         BasicDataset.preprocess(None, Image.fromarray(m), 0.01, is_mask=False)
+
+
+def test_pack_plan_equals_per_layer_packing():
+    """blocks.pack_all (one launch for every conv weight) writes exactly what per-layer unetk_pack_weight writes, for
+    both dtypes and with/without the dgrad streams, and follows in-place weight updates."""
+    from unet import UNet
+    from unetk import blocks, ops
+    net = load_closed_form(UNet(3, 2, False)).cuda()
+    for dtype in (torch.bfloat16, torch.float32):
+        for need_dgrad in (False, True):
+            blocks.pack_all(net, dtype, need_dgrad)
+            n_checked = 0
+            for m in net.modules():
+                cache = m.__dict__.get('_unetk_pack', {})
+                for (kind, dt), (ver, ptr, buf) in cache.items():
+                    if dt != dtype:
+                        continue
+                    ref = ops.pack_weight(kind, m.weight, m.out_channels, m.in_channels, dtype)
+                    assert ver == m.weight._version and ptr == m.weight.data_ptr()
+                    assert torch.equal(buf, ref), (type(m).__name__, kind)
+                    n_checked += 1
+            assert n_checked >= (21 if not need_dgrad else 42)
+    w = net.up1.up.weight
+    with torch.no_grad():
+        w.mul_(2.0)
+    blocks.pack_all(net, torch.bfloat16, True)
+    _, _, buf = net.up1.up.__dict__['_unetk_pack'][(2, torch.bfloat16)]
+    assert torch.equal(buf, ops.pack_weight(2, w, net.up1.up.out_channels, net.up1.up.in_channels, torch.bfloat16))
