@@ -48,7 +48,7 @@ int unetk_pack_weight(int kind, const float* src, void* dst, int c_out, int c_in
 
 /* All weights of a network in one launch.  unetk_pack_plan_build() translates n_items (parameter, packed buffer,
  * kind, channels, dtype) records -- the arguments of n_items unetk_pack_weight() calls -- into an opaque plan in a
- * HOST buffer of unetk_pack_plan_bytes(n_items) bytes and returns the total number of 16-byte pieces (> 0) or an
+ * HOST buffer of unetk_pack_plan_bytes(n_items) bytes and returns the total number of work items (> 0) or an
  * error code; the caller copies the plan to the device once and calls unetk_pack_plan_run() after every optimizer
  * step.  The plan stays valid while the pointers it names do. */
 typedef struct {
@@ -58,7 +58,7 @@ typedef struct {
 } unetk_pack_item;
 int64_t unetk_pack_plan_bytes(int n_items);
 int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* plan_host, int64_t plan_bytes);
-int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_pieces, void* stream);
+int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_items, void* stream);
 
 /* ---- conv3x3, stride 1, pad 1, no bias: unet_parts.py:16,19 (aten::conv2d) -------------------
  * y[n,y,x,co] = sum_{kh,kw,ci} x[n,y+kh-1,x+kw-1,ci] * w[co,ci,kh,kw]      (zero padding)
@@ -69,6 +69,13 @@ int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_pieces,
 #define UNETK_STAT_REPLICAS 32
 int unetk_conv3x3_fprop(const void* x, int ldx, int x_choff, const void* wpk, void* y, int ldy, int y_choff,
                         double* stats, int n, int h, int w, int c_in, int c_out, int dtype, void* stream);
+/* The eval()-mode chain of unet_parts.py:16-18 / 19-21 in one kernel (evaluate.py:10, predict.py:20 put the
+ * net in eval mode): y = relu(scale[c] * conv3x3(x) + shift[c]) with scale/shift from unetk_bn_eval_params
+ * (running statistics).  The affine + ReLU run on the fp32 accumulators in the epilogue; no pre-BN tensor is
+ * written.  bf16 only (UNETK_ERR_DTYPE otherwise: use unetk_conv3x3_fprop + unetk_bn_relu_apply). */
+int unetk_conv3x3_fprop_bn_relu(const void* x, int ldx, int x_choff, const void* wpk, const float* scale,
+                                const float* shift, void* y, int ldy, int y_choff, int n, int h, int w, int c_in,
+                                int c_out, int dtype, void* stream);
 /* dgrad of the same layer (autograd of unet_parts.py:16,19): dx = conv3x3(dy, rot180(w)^T).
  * `wpk` = unetk_pack_weight(kind 1); c_in/c_out are those of the FORWARD layer. */
 int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,

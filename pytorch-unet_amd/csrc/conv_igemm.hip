@@ -31,6 +31,8 @@ struct ConvParams {
   const void* wpk;
   void* y;
   const float* bias;
+  const float* aff_scale;   // conv3x3 AFF instantiations: y = relu(scale[c] * conv + shift[c]) (eval-mode BatchNorm2d + ReLU)
+  const float* aff_shift;
   double* stats;
   int N, H, W;       // tile grid domain (CONV3: image; PWT/CTD: the low-res grid)
   int Cin, Cout;     // GEMM K channels per tap, GEMM N channels
@@ -336,7 +338,7 @@ __device__ uint4 g_zero_page_conv[8];
 // every second weight chunk: every 128-byte line of the activation is then fetched from L2 twice per tile instead
 // of four times (a 16-channel chunk uses 32 B of each pixel's line; TCC_REQ showed 25 M of the 37 M requests of a
 // 512->512 launch were such quarter-used lines, and the fill path is what the MFMA phase waits for).
-template <typename T, int NB, int KS, int NW, int MB, int KI>
+template <typename T, int NB, int KS, int NW, int MB, int KI, bool AFF>
 __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   constexpr int E = ElemTraits<T>::E;
   static_assert(KI % KS == 0, "input buffer = whole number of weight chunks");
@@ -444,6 +446,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   StatAcc tsum[NB], tsq[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) tsum[nb] = tsq[nb] = 0;
+  // AFF: the eval-mode BatchNorm2d + ReLU of the inference path folded into the store (no statistics, no second pass)
+  float asc[NB], ash[NB];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { asc[nb] = P.aff_scale[ch0 + nb]; ash[nb] = P.aff_shift[ch0 + nb]; }
+  }
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int ic = 0; ic < nin; ++ic) {
@@ -536,10 +544,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
           float v[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
-            v[nb] = f;
-            ssum[nb] += f;
-            ssq[nb] += f * f;
+            if constexpr (AFF) {
+              v[nb] = fmaxf(fmaf(acc[mb][nb][i], asc[nb], ash[nb]), 0.f);
+            } else {
+              const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
+              v[nb] = f;
+              ssum[nb] += f;
+              ssq[nb] += f * f;
+            }
           }
           if (!(P.dbg & 4)) store_channels<T, NB>(rowp + ri * P.ldy + lane_off, v);
         }
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   }
 
   // ---- one LDS reduction and one set of fp64 atomics per workgroup
-  if (P.stats != nullptr) {
+  if (!AFF && P.stats != nullptr) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       tsum[nb] += __shfl_xor(tsum[nb], 32, 64);
@@ -577,9 +589,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   }
 }
 
-template <typename T, int NB, int KS, int NW, int MB = 2, int KI = KS> int launch_db(const ConvParams& P, hipStream_t s) {
+template <typename T, int NB, int KS, int NW, int MB = 2, int KI = KS, bool AFF = false>
+int launch_db(const ConvParams& P, hipStream_t s) {
   constexpr size_t lds = 2 * ((size_t)(((MB * NW + 2) * 34 * 2 * KI + 63) / 64) * 1024 + 9 * KS * NB * 1024);
-  UNETK_ALLOW_LDS((conv3x3_db_kernel<T, NB, KS, NW, MB, KI>), lds);
+  UNETK_ALLOW_LDS((conv3x3_db_kernel<T, NB, KS, NW, MB, KI, AFF>), lds);
   ConvParams Q = P;
   Q.tiles_y = host_cdiv(P.H, MB * NW);
   const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
@@ -595,7 +608,7 @@ template <typename T, int NB, int KS, int NW, int MB = 2, int KI = KS> int launc
   Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW, MB, KI>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
+  hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW, MB, KI, AFF>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -864,6 +877,10 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     const Conv3Config cfg = conv3_config(P.Cout);
     if (gen == 2 || cfg.NB == 4) {
       if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+      if (P.aff_scale != nullptr) {     // inference epilogue (bf16 only: BASELINE.json configs[2])
+        if (dtype != UNETK_BF16) return UNETK_ERR_DTYPE;
+        return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2, true>(P, s) : launch_db<bf16, 2, 2, 8, 2, 2, true>(P, s);
+      }
       static const int ki = getenv("UNETK_CONV_KI") ? atoi(getenv("UNETK_CONV_KI")) : 2;   // 1: A/B against 32-B input rows
       if (cfg.NB == 4 && ki == 2)
         return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
@@ -901,12 +918,13 @@ int check_common(const void* x, int ldx, int xoff, const void* y, int ldy, int y
 }
 
 int conv3x3_common(const void* x, int ldx, int xoff, const void* wpk, void* y, int ldy, int yoff, double* stats,
-                   int n, int h, int w, int cin, int cout, int dtype, void* stream) {
+                   int n, int h, int w, int cin, int cout, int dtype, void* stream, const float* aff_scale = nullptr,
+                   const float* aff_shift = nullptr) {
   if (n <= 0 || h <= 0 || w <= 0 || !x || !wpk || !y) return UNETK_ERR_ARG;
   if (int e = check_common(x, ldx, xoff, y, ldy, yoff, cin, cout, dtype, 64)) return e;
   if ((long)h * w * (ldx > ldy ? ldx : ldy) >= 0x7fffffffL) return UNETK_ERR_SHAPE;   // int32 in-image offsets
   ConvParams P{};
-  P.x = x; P.wpk = wpk; P.y = y; P.stats = stats;
+  P.x = x; P.wpk = wpk; P.y = y; P.stats = stats; P.aff_scale = aff_scale; P.aff_shift = aff_shift;
   P.N = n; P.H = h; P.W = w; P.Cin = cin; P.Cout = cout;
   P.ldx = ldx; P.ldy = ldy; P.xoff = xoff; P.yoff = yoff;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = cout / 64;
@@ -920,6 +938,14 @@ extern "C" {
 int unetk_conv3x3_fprop(const void* x, int ldx, int x_choff, const void* wpk, void* y, int ldy, int y_choff,
                         double* stats, int n, int h, int w, int c_in, int c_out, int dtype, void* stream) {
   return conv3x3_common(x, ldx, x_choff, wpk, y, ldy, y_choff, stats, n, h, w, c_in, c_out, dtype, stream);
+}
+
+int unetk_conv3x3_fprop_bn_relu(const void* x, int ldx, int x_choff, const void* wpk, const float* scale,
+                                const float* shift, void* y, int ldy, int y_choff, int n, int h, int w, int c_in,
+                                int c_out, int dtype, void* stream) {
+  if (!scale || !shift) return UNETK_ERR_ARG;
+  return conv3x3_common(x, ldx, x_choff, wpk, y, ldy, y_choff, nullptr, n, h, w, c_in, c_out, dtype, stream, scale,
+                        shift);
 }
 
 int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,

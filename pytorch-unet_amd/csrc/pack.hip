@@ -57,41 +57,61 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 struct PlanItem {
   const float* src;
   void* dst;
-  long long piece_begin;     // first 16-byte piece of this item in the concatenated index space
+  long long piece_begin;     // first work item (a group of all taps' pieces) of this entry in the concatenated index space
   int kind, c_out, c_in, dtype;
   int N, K, taps, KS, outer, NB;
   int pad_[2];
 };
 static_assert(sizeof(PlanItem) % 8 == 0, "plain layout");
 
+// One thread packs ALL taps of one (output channel, E consecutive K-channels) group: its reads are the contiguous
+// taps of each (o, i) pair of the PyTorch layout (a 288-byte run for conv3x3 fprop), its writes one 16-byte piece
+// per tap, adjacent lanes writing adjacent pieces of the same fragment.  (One thread per piece re-read every
+// 32-byte sector of the parameter eight times.)
 template <typename T>
-__device__ __forceinline__ void pack_piece(const PlanItem& it, long idx) {
+__device__ __forceinline__ void pack_group(const PlanItem& it, long gidx) {
   constexpr int E = ElemTraits<T>::E;
   const int CH = 2 * it.KS * E;
   const int nchunks = it.K / CH;
-  const int lane = (int)(idx & 63);
-  long f = idx >> 6;
+  const int ntap = it.taps * it.outer;             // 9 (conv3x3) or 4 (convT: as inner taps for fwd, outer for dgrad)
+  const int lane = (int)(gidx & 63);
+  long f = gidx >> 6;
   const int nb = (int)(f % it.NB); f /= it.NB;
   const int ks = (int)(f % it.KS); f /= it.KS;
-  const int tap_in = (int)(f % it.taps); f /= it.taps;
   const int kc = (int)(f % nchunks); f /= nchunks;
-  const int tap_out = (int)(f % it.outer); f /= it.outer;
   const int nt = (int)f;
-  const int tap = it.outer > 1 ? tap_out : tap_in;
   const int j = lane & 31, h = lane >> 5;
   const int o = nt * 32 * it.NB + it.NB * j + nb;
-  T out[E];
+  const int i0 = kc * CH + ks * 2 * E + h * E;
+  float v[E][9];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int i = kc * CH + ks * 2 * E + h * E + e;
-    long s;
-    if (it.kind == 0) s = ((long)o * it.c_in + i) * 9 + tap;
-    else if (it.kind == 1) s = ((long)i * it.c_in + o) * 9 + (8 - tap);
-    else if (it.kind == 2) { const int ab = o / it.c_out, co = o - ab * it.c_out; s = ((long)i * it.c_out + co) * 4 + ab; }
-    else s = ((long)o * it.c_out + i) * 4 + tap;
-    out[e] = from_f32<T>(it.src[s]);
+    const int i = i0 + e;
+    long base;
+    if (it.kind == 0) base = ((long)o * it.c_in + i) * 9;
+    else if (it.kind == 1) base = ((long)i * it.c_in + o) * 9;
+    else if (it.kind == 2) { const int ab = o / it.c_out, co = o - ab * it.c_out; base = ((long)i * it.c_out + co) * 4 + ab; }
+    else base = ((long)o * it.c_out + i) * 4;
+    if (it.kind == 2) {
+      v[e][0] = it.src[base];                      // the tap is part of the GEMM-N index: one value per (o, i)
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (t < ntap) v[e][t] = it.src[base + t];
+    }
   }
-  *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + idx * E) = *reinterpret_cast<const uint4*>(out);
+  // fragment index = ((((nt*outer + tap_out)*nchunks + kc)*taps + tap_in)*KS + ks)*NB + nb
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t >= ntap) continue;
+    const int tap_out = it.outer > 1 ? t : 0, tap_in = it.outer > 1 ? 0 : t;
+    const int tsrc = it.kind == 1 ? 8 - t : t;     // dgrad: rotated kernel
+    const long frag = (((((long)nt * it.outer + tap_out) * nchunks + kc) * it.taps + tap_in) * it.KS + ks) * it.NB + nb;
+    T out[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = from_f32<T>(it.kind == 2 ? v[e][0] : v[e][tsrc]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + (frag * 64 + lane) * E) = *reinterpret_cast<const uint4*>(out);
+  }
 }
 
 __global__ __launch_bounds__(256) void pack_plan_kernel(const PlanItem* __restrict__ plan, int n_items, long total) {
@@ -102,8 +122,8 @@ __global__ __launch_bounds__(256) void pack_plan_kernel(const PlanItem* __restri
       if (plan[mid].piece_begin <= idx) lo = mid; else hi = mid - 1;
     }
     const PlanItem it = plan[lo];
-    if (it.dtype == UNETK_BF16) pack_piece<bf16>(it, idx - it.piece_begin);
-    else pack_piece<float>(it, idx - it.piece_begin);
+    if (it.dtype == UNETK_BF16) pack_group<bf16>(it, idx - it.piece_begin);
+    else pack_group<float>(it, idx - it.piece_begin);
   }
 }
 
@@ -130,7 +150,7 @@ int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* p
     p.kind = u.kind; p.c_out = u.c_out; p.c_in = u.c_in; p.dtype = u.dtype;
     p.N = g.N; p.K = g.K; p.taps = g.taps; p.KS = g.KS; p.outer = g.outer; p.NB = g.NB;
     plan[i] = p;
-    total += bytes / 16;
+    total += bytes / 16 / (g.taps * g.outer);      // one work item per (all taps of a 16-byte K group)
   }
   return total;
 }

@@ -124,6 +124,23 @@ def conv3x3_fprop(x, wpk, c_out, out=None, stats=None):
     return out
 
 
+def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None):
+    """relu(scale * conv3x3(x) + shift) in one kernel (eval-mode BatchNorm folded into the conv epilogue; bf16)."""
+    require_cuda(x, wpk)
+    n, h, w, c_in, ldx = nhwc_meta(x, 'conv3x3 input')
+    if out is None:
+        out = new_nhwc(n, h, w, c_out, x.dtype, x.device)
+    on, oh, ow, oc, ldy = nhwc_meta(out, 'conv3x3 output')
+    if (on, oh, ow, oc) != (n, h, w, c_out) or out.dtype != x.dtype or wpk.dtype != x.dtype:
+        raise RuntimeError('conv3x3: output/weight do not match the input')
+    if wpk.numel() != 9 * c_in * c_out or state.scale.numel() != c_out:
+        raise RuntimeError('conv3x3: packed weight / BatchNorm coefficients have the wrong size')
+    check(fn['unetk_conv3x3_fprop_bn_relu'](x.data_ptr(), ldx, 0, wpk.data_ptr(), state.scale.data_ptr(),
+                                            state.shift.data_ptr(), out.data_ptr(), ldy, 0, n, h, w, c_in, c_out,
+                                            dtype_code(x.dtype), stream_ptr()), 'unetk_conv3x3_fprop_bn_relu')
+    return out
+
+
 def conv3x3_dgrad(dy, wpk_d, c_in, out=None):
     require_cuda(dy, wpk_d)
     n, h, w, c_out, lddy = nhwc_meta(dy, 'conv3x3 dgrad input')
@@ -320,6 +337,16 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None):
 
 
 # ------------------------------------------------------------------------------------ max pool
+def maxpool_into(x, pool_out):
+    n, h, w, c, ldx = nhwc_meta(x, 'pool input')
+    pn, ph, pw, pc, ldp = nhwc_meta(pool_out, 'pool output')
+    if (pn, ph, pw, pc) != (n, h // 2, w // 2, c) or pool_out.dtype != x.dtype:
+        raise RuntimeError('maxpool: pool_out must be [N, H//2, W//2, C] of the activation dtype')
+    check(fn['unetk_maxpool2x2_fwd'](x.data_ptr(), ldx, pool_out.data_ptr(), ldp, n, h, w, c, dtype_code(x.dtype),
+                                     stream_ptr()), 'unetk_maxpool2x2_fwd')
+    return pool_out
+
+
 def maxpool_fwd(x):
     n, h, w, c, ldx = nhwc_meta(x, 'pool input')
     out = new_nhwc(n, h // 2, w // 2, c, x.dtype, x.device)

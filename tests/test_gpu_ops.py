@@ -368,3 +368,37 @@ def test_bn_relu_apply_pool_equals_apply_then_pool(dtype, n, h, w, c):
     out = ops.bn_relu_apply(y, st, out=cat[..., :c], pool_out=pool)
     assert torch.equal(out, ref) and torch.equal(pool, ref_pool)
     assert torch.equal(cat[..., c:], torch.full_like(cat[..., c:], 7.0))
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 64), (128, 64), (64, 128), (256, 256)])
+def test_conv3x3_fprop_bn_relu_equals_conv_then_eval_bn(cin, cout):
+    """Inference epilogue (eval-mode BatchNorm2d + ReLU folded into the conv, unet_parts.py:16-18 under net.eval()):
+    against torch's fp32 conv -> batch_norm(running stats) -> relu on the same bf16-rounded operands (bar: one bf16
+    rounding of the result, 2^-8 relative + a small absolute term for cancellation), and against the two-pass path
+    (which additionally rounds the pre-BN tensor to bf16)."""
+    import torch.nn.functional as F
+    from unetk import ops
+    torch.manual_seed(cin * 1000 + cout)
+    n, h, w = 2, 21, 37                                  # ragged against the 16x32 tiles
+    x = torch.randn((n, h, w, cin), device='cuda').bfloat16()
+    wt = (torch.randn((cout, cin, 3, 3), device='cuda') * (2.0 / (9 * cin)) ** 0.5)
+    bn = torch.nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.3, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    wpk = ops.pack_weight(0, wt, cout, cin, torch.bfloat16)
+    st = ops.BNState(cout, 'cuda')
+    ops.bn_eval_params(bn, st, bn.eps)
+    cat = torch.full((n, h, w, cout + 64), 7.0, dtype=torch.bfloat16, device='cuda')   # output = channel slice
+    got = ops.conv3x3_fprop_bn_relu(x, wpk, cout, st, out=cat[..., :cout])
+    assert torch.equal(cat[..., cout:].float(), torch.full((n, h, w, 64), 7.0, device='cuda')), 'wrote past its slice'
+    with torch.no_grad():
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt.bfloat16().float(), padding=1)
+        ref = F.relu(bn(y)).permute(0, 2, 3, 1)
+    err = (got.float() - ref).abs()
+    assert float((err - (2.0 ** -8) * ref.abs()).max()) < 2e-3
+    two = ops.bn_relu_apply(ops.conv3x3_fprop(x, wpk, cout), st)
+    assert float(((two.float() - got.float()).abs() - (2.0 ** -6) * got.float().abs()).max()) < 2e-2
+    assert float((two.float() - got.float()).abs().mean()) < 2e-3
