@@ -94,6 +94,11 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
  * Reads the fp32 NHWC image directly (train.py:97 hands over fp32 channels_last) and the UNPACKED parameter. */
 int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
                               int wd, int c_in, int c_out, int dtype, void* stream);
+/* Same layer under net.eval() (evaluate.py:10, predict.py:20): y = relu(scale[c] * conv + shift[c]), the eval-mode
+ * BatchNorm2d + ReLU of unet_parts.py:17-18 folded into the store (scale/shift from unetk_bn_eval_params). */
+int unetk_conv3x3_first_fprop_bn_relu(const float* x, int ldx, const float* w, const float* scale, const float* shift,
+                                      void* y, int ldy, int n, int h, int wd, int c_in, int c_out, int dtype,
+                                      void* stream);
 int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out);
 int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                               int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,

@@ -17,6 +17,8 @@ struct FirstParams {
   const float* w;     // parameter [Cout][Cin][3][3]
   void* y;
   double* stats;
+  const float* aff_scale;   // != NULL: y = relu(scale[c] * conv + shift[c]) (eval-mode BatchNorm2d + ReLU), no statistics
+  const float* aff_shift;
   int N, H, W, Cin, Cout, ldx, ldy;
   int tiles_x, tiles_y, n_tiles;
 };
@@ -112,6 +114,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
   T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
+  const bool aff = P.aff_scale != nullptr;
+  float asc[NB], ash[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    asc[nb] = aff ? P.aff_scale[ch0 + nb] : 1.f;
+    ash[nb] = aff ? P.aff_shift[ch0 + nb] : 0.f;
+  }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
     const int yy = y0 + 2 * wid + mb;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
-          v[nb] = f;
+          v[nb] = aff ? fmaxf(fmaf(acc[mb][nb][i], asc[nb], ash[nb]), 0.f) : f;
           ssum[nb] += f;
           ssq[nb] += f * f;
         }
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
       }
     }
   }
-  if (P.stats != nullptr) {
+  if (P.stats != nullptr && !aff) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
@@ -411,8 +420,8 @@ int first_nsplit(int ntiles, int col_tiles) {
 
 extern "C" {
 
-int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
-                              int wd, int c_in, int c_out, int dtype, void* stream) {
+static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, const float* scale,
+                       const float* shift, int n, int h, int wd, int c_in, int c_out, int dtype, void* stream) {
   if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
   if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
   if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || ldx < c_in || ldy < c_out) return UNETK_ERR_SHAPE;
@@ -420,7 +429,7 @@ int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, 
   if ((reinterpret_cast<uintptr_t>(y) & 15) || (ldy * es) % 16) return UNETK_ERR_ALIGN;
   if ((long)h * wd * ldy >= 0x7fffffffL) return UNETK_ERR_SHAPE;
   FirstParams P{};
-  P.x = x; P.w = w; P.y = y; P.stats = stats;
+  P.x = x; P.w = w; P.y = y; P.stats = stats; P.aff_scale = scale; P.aff_shift = shift;
   P.N = n; P.H = h; P.W = wd; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.ldy = ldy;
   P.tiles_x = host_cdiv(wd, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = c_out / 64;
   const long nblk = (long)n * P.tiles_x * P.tiles_y * P.n_tiles;
@@ -432,6 +441,18 @@ int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, 
     hipLaunchKernelGGL(conv_first_fprop_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
+}
+
+int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
+                              int wd, int c_in, int c_out, int dtype, void* stream) {
+  return first_fprop(x, ldx, w, y, ldy, stats, nullptr, nullptr, n, h, wd, c_in, c_out, dtype, stream);
+}
+
+int unetk_conv3x3_first_fprop_bn_relu(const float* x, int ldx, const float* w, const float* scale, const float* shift,
+                                      void* y, int ldy, int n, int h, int wd, int c_in, int c_out, int dtype,
+                                      void* stream) {
+  if (!scale || !shift) return UNETK_ERR_ARG;
+  return first_fprop(x, ldx, w, y, ldy, nullptr, scale, shift, n, h, wd, c_in, c_out, dtype, stream);
 }
 
 int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out) {

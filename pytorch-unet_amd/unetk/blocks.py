@@ -127,14 +127,18 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
     batch_stats = _bn_uses_batch_stats(bn)
     n, h, w, _, _ = ops.nhwc_meta(x, 'conv input')
     stats = ops.new_stats(c_out, x.device) if batch_stats else None
-    if not batch_stats and c_in > 4 and dtype == torch.bfloat16:
+    if not batch_stats and (c_in <= 4 or dtype == torch.bfloat16):
         # inference (evaluate.py:10, predict.py:20 call net.eval()): BatchNorm with running statistics is a per-channel
         # affine map -> folded with the ReLU into the conv epilogue, no pre-BN tensor, no second pass
-        if x.dtype != dtype:
-            x = x.to(dtype)
         st = ops.BNState(c_out, x.device)
         ops.bn_eval_params(bn, st, float(bn.eps))
-        act = ops.conv3x3_fprop_bn_relu(x, packed_weight(conv, 0, dtype, c_out, c_in), c_out, st, out=out)
+        if c_in <= 4:
+            x = x if x.dtype == torch.float32 else x.float()
+            act = ops.conv3x3_first_fprop_bn_relu(x, _f32c(conv.weight), c_out, dtype, st, out=out)
+        else:
+            if x.dtype != dtype:
+                x = x.to(dtype)
+            act = ops.conv3x3_fprop_bn_relu(x, packed_weight(conv, 0, dtype, c_out, c_in), c_out, st, out=out)
         if pool_out is not None:
             ops.maxpool_into(act, pool_out)
         return act, (x, None, st)

@@ -207,6 +207,22 @@ def conv3x3_first_fprop(x_f32, w_param, c_out, dtype, out=None, stats=None):
     return out
 
 
+def conv3x3_first_fprop_bn_relu(x_f32, w_param, c_out, dtype, state, out=None):
+    require_cuda(x_f32, w_param)
+    n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    if x_f32.dtype != torch.float32 or w_param.dtype != torch.float32 or not w_param.is_contiguous():
+        raise RuntimeError('first conv: image and parameter must be fp32')
+    if out is None:
+        out = new_nhwc(n, h, w, c_out, dtype, x_f32.device)
+    on, oh, ow, oc, ldy = nhwc_meta(out, 'first conv output')
+    if (on, oh, ow, oc) != (n, h, w, c_out) or out.dtype != dtype or state.scale.numel() != c_out:
+        raise RuntimeError('first conv: output / BatchNorm coefficients do not match')
+    check(fn['unetk_conv3x3_first_fprop_bn_relu'](x_f32.data_ptr(), ldx, w_param.data_ptr(), state.scale.data_ptr(),
+                                                  state.shift.data_ptr(), out.data_ptr(), ldy, n, h, w, c_in, c_out,
+                                                  dtype_code(dtype), stream_ptr()), 'unetk_conv3x3_first_fprop_bn_relu')
+    return out
+
+
 def conv3x3_first_wgrad(x_f32, dy, dw):
     require_cuda(x_f32, dy, dw)
     n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')

@@ -402,3 +402,30 @@ def test_conv3x3_fprop_bn_relu_equals_conv_then_eval_bn(cin, cout):
     two = ops.bn_relu_apply(ops.conv3x3_fprop(x, wpk, cout), st)
     assert float(((two.float() - got.float()).abs() - (2.0 ** -6) * got.float().abs()).max()) < 2e-2
     assert float((two.float() - got.float()).abs().mean()) < 2e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_first_conv_bn_relu_equals_torch_eval_chain(dtype):
+    import torch.nn.functional as F
+    from unetk import ops
+    torch.manual_seed(5)
+    n, h, w, cout = 2, 19, 45, 64
+    x = torch.rand((n, h, w, 3), device='cuda')
+    wt = torch.randn((cout, 3, 3, 3), device='cuda') * 0.3
+    bn = torch.nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.3, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    st = ops.BNState(cout, 'cuda')
+    ops.bn_eval_params(bn, st, bn.eps)
+    got = ops.conv3x3_first_fprop_bn_relu(x, wt, cout, dtype, st)
+    xr, wr = (x.bfloat16().float(), wt.bfloat16().float()) if dtype == torch.bfloat16 else (x, wt)
+    with torch.no_grad():
+        ref = F.relu(bn(F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1))).permute(0, 2, 3, 1)
+    err = (got.float() - ref).abs()
+    if dtype == torch.bfloat16:
+        assert float((err - (2.0 ** -8) * ref.abs()).max()) < 1e-3
+    else:
+        assert float(err.max()) < 2e-5
