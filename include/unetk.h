@@ -233,6 +233,28 @@ int unetk_clip_rmsprop_step(float* param, float* grad, float* square_avg, float*
                             void* workspace, int64_t workspace_bytes, double* total_norm_out, float max_norm, float lr,
                             float alpha, float eps, float weight_decay, float momentum, void* stream);
 
+/* ---- input formatting: BasicDataset.preprocess, utils/data_loading.py:65-91 ----------
+ * The reference resizes on the CPU with Pillow (`pil_img.resize`, :69: BICUBIC for images, NEAREST for masks) and
+ * converts (:72-91).  These entry points do the same on decoded uint8 pixels already in HBM, BIT-EXACTLY
+ * (Pillow's fixed-point two-pass convolution / its NEAREST position tables, restated in csrc/preprocess.hip).
+ *
+ * unetk_resize_plan_build: HOST-side, once per (in size, out size, filter): the per-output-pixel windows and 22-bit
+ *   coefficients (filter 3 = BICUBIC) or source positions (filter 0 = NEAREST) that Pillow precomputes per call.
+ *   plan_host == NULL returns the plan size; otherwise fills `plan_host` and returns the bytes written.  The caller
+ *   copies the plan to the device (`plan_dev`) and passes BOTH to the calls below (the host copy carries the sizes).
+ * unetk_preprocess_image: src [n][in_h][in_w][channels] uint8 -> out [n][out_h][out_w][channels] fp32 (NHWC: what
+ *   the first convolution reads; the reference's CHW is a permuted view), value/255.0 if any value of THAT image
+ *   exceeds 1 (:88-89), else the raw value.  `workspace` of unetk_resize_workspace_bytes() bytes.
+ * unetk_preprocess_mask: src [n][in_h][in_w][channels] uint8 -> out [n][out_h][out_w] int64 = index i of the LAST
+ *   mask_values[i] ([n_values][channels] uint8, device) equal to the NEAREST-resized pixel, 0 if none (:73-78). */
+int64_t unetk_resize_plan_build(int in_w, int in_h, int out_w, int out_h, int filter, void* plan_host,
+                                int64_t plan_bytes);
+int64_t unetk_resize_workspace_bytes(const void* plan_host, int n, int channels);
+int unetk_preprocess_image(const uint8_t* src, int n, int channels, const void* plan_host, const void* plan_dev,
+                           float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int unetk_preprocess_mask(const uint8_t* src, int n, int channels, const void* plan_host, const void* plan_dev,
+                          const uint8_t* mask_values, int n_values, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

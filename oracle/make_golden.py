@@ -322,6 +322,8 @@ for tag, ncls in {'predict_c2': 2, 'predict_c1': 1}.items():
         margin = (torch.sigmoid(up) - 0.5).abs()[0, 0].numpy()
     save(tag, rgb=rgb, preprocessed=img[0].numpy(), mask=out.astype(np.int64), margin=margin.astype(np.float32))
 
+# (section 7, BasicDataset.preprocess, lives in oracle/make_golden_preprocess.py)
+
 # checkpoint file shaped like train.py:163-165 writes it (state_dict + 'mask_values'), tiny variant
 # is impossible (widths are hard-coded), so only the key manifest above pins the layout.
 print('done')

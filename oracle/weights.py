@@ -50,6 +50,18 @@ def int_wave(name: str, shape, n_values: int):
     return np.ascontiguousarray(v[..., :shape[-2], :shape[-1]])
 
 
+def photo(tag: str, h: int, w: int, c: int):
+    """uint8 test image [h,w,c] ([h,w] for c == 1): 60 % hashed noise (worst case for the cubic's negative lobes,
+    exercises the 8-bit clipping) + 40 % integer triangle wave.  Integer / IEEE mult-add only: identical everywhere."""
+    shape = (h, w, c) if c > 1 else (h, w)
+    noise = wave(tag + '.noise', shape, 0.5, 0.5, dtype=np.float64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.abs(((xx * 9 + yy * 5) % 510) - 255).astype(np.float64)
+    if c > 1:
+        smooth = smooth[..., None]
+    return np.clip(0.6 * 255.0 * noise + 0.4 * smooth, 0, 255).astype(np.uint8)
+
+
 def tensor_for_key(key: str, shape, dtype_name: str):
     """Value for one state_dict entry, by the role its key names (row S of SURVEY 8a)."""
     leaf = key.rsplit('.', 1)[-1]

@@ -4,6 +4,9 @@ Only `BasicDataset.preprocess` -- the one piece of the reference's dataset class
 and the training loader share -- is provided: PIL image -> resized float CHW array in [0,1] (BICUBIC), or PIL mask ->
 int64 class-index map (NEAREST).  File discovery, the multiprocessing scan for mask values and the Dataset
 plumbing are control plane around the path.
+
+`BasicDataset.preprocess_gpu` is the same function on decoded uint8 pixels already in HBM (one frame or a batch):
+bit-exact with the PIL path (unetk/preprocess.py, csrc/preprocess.hip), for loaders that ship raw frames to the GPU.
 """
 import numpy as np
 from PIL import Image
@@ -27,3 +30,12 @@ class BasicDataset:
         if (img > 1).any():
             img = img / 255.0
         return img
+
+    @staticmethod
+    def preprocess_gpu(mask_values, pixels, scale, is_mask):
+        """preprocess() for a CUDA uint8 tensor `pixels` = np.asarray(pil_img) ([H,W] / [H,W,C], or [N,H,W,C]).
+        Returns CUDA tensors: float32 [C,H',W'] (NHWC-backed) or int64 [H',W']; a leading N for batches."""
+        from unetk import preprocess as P
+        if is_mask:
+            return P.preprocess_mask(pixels, mask_values, scale)
+        return P.preprocess_image(pixels, scale)
