@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 
 class FlatGrads:
-    def __init__(self, net, process_group=None, bucket_bytes=25 << 20):
+    def __init__(self, net, process_group=None, bucket_bytes=25 << 20, force_collectives=False):
         self.params = list(reversed(net.hot_path_params()))   # approximate completion order; ranges are re-derived
         order = []
         for blk in self._completion_blocks(net):
@@ -27,8 +27,11 @@ class FlatGrads:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
+        # force_collectives: run the bucketed all-reduces even in a 1-rank group (rehearses the RCCL path -- stream
+        # hand-over, bucket ranges -- on a single GPU; the average over one rank is the identity)
+        self.active = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
         # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum and divide after the wait
-        self.native_avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'
+        self.native_avg = self.active and dist.get_backend(process_group) == 'nccl'
         self.flat = None
         self._pending = [0, 0]
         self._works = []
@@ -61,7 +64,7 @@ class FlatGrads:
         hi = max(self.offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in params)
         assert lo == self._pending[1], 'blocks must complete in layout order'
         self._pending[1] = hi
-        if self.world > 1 and hi - self._pending[0] >= self.bucket_elems:
+        if self.active and hi - self._pending[0] >= self.bucket_elems:
             self._launch()
 
     def _launch(self):
@@ -73,7 +76,7 @@ class FlatGrads:
 
     def finish(self):
         """Call after backward(): flush the last bucket and make the compute stream wait for every all-reduce."""
-        if self.world > 1:
+        if self.active:
             self._launch()
             for w, lo, hi in self._works:
                 w.wait()

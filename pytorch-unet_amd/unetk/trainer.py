@@ -18,11 +18,11 @@ from .loss import segmentation_loss
 
 class Trainer:
     def __init__(self, net, learning_rate=1e-5, weight_decay=1e-8, momentum=0.999, gradient_clipping=1.0, amp=True,
-                 process_group=None, bucket_bytes=25 << 20, fused_optimizer=True):
+                 process_group=None, bucket_bytes=25 << 20, fused_optimizer=True, force_collectives=False):
         self.net = net
         self.amp = amp
         self.clip = gradient_clipping
-        self.sync = FlatGrads(net, process_group, bucket_bytes)
+        self.sync = FlatGrads(net, process_group, bucket_bytes, force_collectives)
         self.fused = fused_optimizer
         if fused_optimizer:
             from .optim import ClipRMSprop
