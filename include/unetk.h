@@ -153,6 +153,16 @@ int unetk_bn_relu_bwd_finalize(const double* sums, int64_t count, const float* g
 int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,
                             const float* mean, const float* coef, void* dy, int lddy, int64_t npix, int c, int dtype,
                             void* stream);
+/* The same two passes for an ENCODER block's last layer, whose output feeds the skip connection AND MaxPool2d(2)
+ * (unet_model.py:26-30, unet_parts.py:34): dout = dskip + scatter(dpool -> first maximum of each 2x2 window) is formed
+ * on the fly from dskip [n][h][w] and dpool [n][h/2][w/2] (the arg-max is recomputed from y), so no max-pool
+ * backward pass runs.  UNETK_ERR_SHAPE when c/(16/es) does not divide 256: use unetk_maxpool2x2_bwd + the calls above. */
+int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  double* sums, int n, int h, int w, int c, int dtype, void* stream);
+int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy,
+                                 const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
+                                 int lddy, int n, int h, int w, int c, int dtype, void* stream);
 
 /* ---- MaxPool2d(2): unet_parts.py:34 (aten::max_pool2d), floor mode ---------------------------------------------
  * bwd: dx = (dskip ? dskip : 0) + dpool routed to the first maximum of each window; `dskip` is the gradient the

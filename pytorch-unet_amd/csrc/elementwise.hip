@@ -365,6 +365,165 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_fixed_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------ BN + ReLU backward
+// of an ENCODER block's second layer, whose output feeds both the skip connection and MaxPool2d(2)
+// (unet_model.py:26-30): its gradient is  dskip + scatter(dpool to the first maximum of each 2x2 window).  These two
+// variants form that sum on the fly -- one thread owns a 2x2 pixel quad x one 16-byte channel piece, recomputes the
+// four stored activations relu(bn(y)) (rounded to T, which is what MaxPool2d compared) and their arg-max -- so the
+// max-pool backward pass (read x, dskip, dpool, write dx: 3.25 tensor passes) disappears; the BN kernels read
+// dpool (a quarter tensor) instead.
+// The quad's operands stay packed (16-byte registers) until the element they belong to is processed.  Measured
+// (scripts/perf_bn_pool.py): letting hipcc take ~195 VGPRs (2 waves/SIMD, no scratch) runs at 4.8-5.5 TB/s; capping
+// it at 128 or 170 VGPRs by launch bounds spills and drops to 3.4-4.3 TB/s.
+template <typename T> __device__ __forceinline__ float raw_elem(const uint4& r, int i);
+template <> __device__ __forceinline__ float raw_elem<bf16>(const uint4& r, int i) {
+  const unsigned w = (i >> 1) == 0 ? r.x : (i >> 1) == 1 ? r.y : (i >> 1) == 2 ? r.z : r.w;
+  return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+template <> __device__ __forceinline__ float raw_elem<float>(const uint4& r, int i) {
+  return __uint_as_float(i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w);
+}
+template <typename T> __device__ __forceinline__ uint4 raw_load(const T* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+}
+
+template <typename T>
+struct QuadGrad {
+  static constexpr int E = Vec<T>::E;
+  uint4 v[4], g[4], gp;
+  bool hx, hy;
+  __device__ __forceinline__ bool has(int k) const { return (!(k & 1) || hx) && (!(k >> 1) || hy); }
+  __device__ __forceinline__ void load(const T* __restrict__ dskip, int ldds, const T* __restrict__ dpool, int lddp,
+                                       const T* __restrict__ y, int ldy, long n, int qy, int qx, int H, int W, int c0) {
+    const int y0 = 2 * qy, x0 = 2 * qx;
+    hx = x0 + 1 < W;
+    hy = y0 + 1 < H;
+    const long p00 = (n * H + y0) * W + x0;
+    // clamped addresses instead of branches: an absent pixel re-reads pixel 0 of the quad and is masked on use
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long p = p00 + (((k >> 1) && hy) ? W : 0) + (((k & 1) && hx) ? 1 : 0);
+      v[k] = raw_load(y + p * ldy + c0);
+      g[k] = raw_load(dskip + p * ldds + c0);
+    }
+    const int py = hy ? qy : max(qy - 1, 0), px = hx ? qx : max(qx - 1, 0);      // any valid pooled pixel
+    gp = raw_load(dpool + ((n * (H / 2) + py) * (W / 2) + px) * lddp + c0);
+  }
+  // full output gradient of the quad's four pixels for channel element i, and the pre-BN values
+  __device__ __forceinline__ void element(int i, float sc, float sh, float (&yv)[4], float (&gv)[4]) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { yv[k] = raw_elem<T>(v[k], i); gv[k] = raw_elem<T>(g[k], i); }
+    if (hx && hy) {       // complete window (floor mode drops an odd last row / column)
+      int a = 0;
+      float m = to_f32(from_f32<T>(fmaxf(fmaf(yv[0], sc, sh), 0.f)));
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float ak = to_f32(from_f32<T>(fmaxf(fmaf(yv[k], sc, sh), 0.f)));
+        if (ak > m) { m = ak; a = k; }
+      }
+      const float gpi = raw_elem<T>(gp, i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gv[k] += (a == k) ? gpi : 0.f;
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
+    const T* __restrict__ dskip, int ldds, const T* __restrict__ dpool, int lddp, const T* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, double* sums, int N, int H, int W, int C) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[256 * E * 2];
+  const int ppp = C / E;                      // <= 256 and a divisor of 256 (checked by the host)
+  const int lanes = 256 / ppp;
+  const int piece = threadIdx.x % ppp, plane = threadIdx.x / ppp;
+  const int c0 = piece * E;
+  for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float sc[E], sh[E], mu[E], is[E], s1[E], s2[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+    s1[i] = s2[i] = 0.f;
+  }
+  const int QH = (H + 1) / 2, QW = (W + 1) / 2;
+  const long nquads = (long)N * QH * QW;
+  for (long q = (long)blockIdx.x * lanes + plane; q < nquads; q += (long)gridDim.x * lanes) {
+    const int qx = (int)(q % QW);
+    const long r = q / QW;
+    const int qy = (int)(r % QH);
+    QuadGrad<T> Q;
+    Q.load(dskip, ldds, dpool, lddp, y, ldy, r / QH, qy, qx, H, W, c0);
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      float yv[4], gv[4];
+      Q.element(i, sc[i], sh[i], yv, gv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dz = (Q.has(k) && fmaf(yv[k], sc[i], sh[i]) > 0.f) ? gv[k] : 0.f;
+        s1[i] += dz;
+        s2[i] += dz * (yv[k] - mu[i]) * is[i];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one channel element at a time
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], s2[i]);
+  }
+  __syncthreads();
+  double* dst = sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C * 2;
+  for (int i = threadIdx.x; i < C * 2; i += 256) unsafeAtomicAdd(dst + i, (double)red[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_pool_kernel(
+    const T* __restrict__ dskip, int ldds, const T* __restrict__ dpool, int lddp, const T* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ coef, T* __restrict__ dy, int lddy, int N, int H, int W, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const int lanes = 256 / ppp;
+  const int c0 = (threadIdx.x % ppp) * E;
+  const int plane = threadIdx.x / ppp;
+  float sc[E], sh[E], mu[E], ka[E], kb[E], kc[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i];
+    ka[i] = coef[c0 + i]; kb[i] = coef[C + c0 + i]; kc[i] = coef[2 * C + c0 + i];
+  }
+  const int QH = (H + 1) / 2, QW = (W + 1) / 2;
+  const long nquads = (long)N * QH * QW;
+  for (long q = (long)blockIdx.x * lanes + plane; q < nquads; q += (long)gridDim.x * lanes) {
+    const int qx = (int)(q % QW);
+    const long r = q / QW;
+    const int qy = (int)(r % QH);
+    const long n = r / QH;
+    QuadGrad<T> Q;
+    Q.load(dskip, ldds, dpool, lddp, y, ldy, n, qy, qx, H, W, c0);
+    float o[4][E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      float yv[4], gv[4];
+      Q.element(i, sc[i], sh[i], yv, gv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dz = fmaf(yv[k], sc[i], sh[i]) > 0.f ? gv[k] : 0.f;
+        o[k][i] = ka[i] * dz - kb[i] - kc[i] * (yv[k] - mu[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one channel element at a time
+    }
+    const long p00 = (n * H + 2 * qy) * W + 2 * qx;
+    Vec<T>::store(dy + p00 * lddy + c0, o[0]);
+    if (Q.hx) Vec<T>::store(dy + (p00 + 1) * lddy + c0, o[1]);
+    if (Q.hy) Vec<T>::store(dy + (p00 + W) * lddy + c0, o[2]);
+    if (Q.hx && Q.hy) Vec<T>::store(dy + (p00 + W + 1) * lddy + c0, o[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ MaxPool2d(2)
 // unet_parts.py:34: k2 s2, floor mode -- an odd last row/column is dropped.
 template <typename T>
@@ -771,6 +930,50 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
                          (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy, lddy, (long)npix, c);
   });
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+static int pool_bwd_check(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy, int n,
+                          int h, int w, int c, int dtype) {
+  if (!dskip || !dpool || !y || n <= 0 || h < 2 || w < 2 || c <= 0) return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  if (c % E || c / E > 256 || 256 % (c / E)) return UNETK_ERR_SHAPE;   // callers fall back to max-pool backward + plain BN backward
+  if (ldds < c || lddp < c || ldy < c) return UNETK_ERR_SHAPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if ((ldds * es) % 16 || (lddp * es) % 16 || (ldy * es) % 16) return UNETK_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(dskip) | reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(y)) & 15)
+    return UNETK_ERR_ALIGN;
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  double* sums, int n, int h, int w, int c, int dtype, void* stream) {
+  if (int e = pool_bwd_check(dskip, ldds, dpool, lddp, y, ldy, n, h, w, c, dtype)) return e;
+  if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dskip, ldds, (const T*)dpool, lddp, (const T*)y, ldy, scale, shift, mean,
+                                       invstd, sums, n, h, w, c));
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy,
+                                 const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
+                                 int lddy, int n, int h, int w, int c, int dtype, void* stream) {
+  if (int e = pool_bwd_check(dskip, ldds, dpool, lddp, y, ldy, n, h, w, c, dtype)) return e;
+  if (!scale || !shift || !mean || !coef || !dy || lddy < c) return UNETK_ERR_ARG;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dskip, ldds, (const T*)dpool, lddp, (const T*)y, ldy, scale, shift, mean,
+                                       coef, (T*)dy, lddy, n, h, w, c));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -92,16 +92,22 @@ class _UNetImpl:
             dcats[k] = dcat
             d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True)
             done(blocks.up_params(up))
-        # encoder, deepest first; the skip gradient (first half of dcat) joins in the pool backward, in place
+        # encoder, deepest first.  A block's output fed the skip connection and the next block's max-pool: its
+        # gradient = first half of dcat + scatter(pool gradient), formed inside the BatchNorm backward kernels
+        dpool = None
         for k in (4, 3, 2, 1, 0):
             need_dx = k > 0 or needs[0]
-            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx)
+            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx, dpool=dpool)
             done(blocks.double_conv_params(enc[k]))
+            dpool = None
             if k > 0:
                 dcat = dcats[4 - k]
                 c_skip = saved['cats'][4 - k]
                 dskip = dcat[..., :c_skip]
-                d = ops.maxpool_bwd(saved['pool_in'][k - 1], d, dskip, out=dskip)
+                if ops.pool_bwd_fusable(c_skip, dskip.dtype):
+                    d, dpool = dskip, d
+                else:
+                    d = ops.maxpool_bwd(saved['pool_in'][k - 1], d, dskip, out=dskip)
         return (d,)
 
 

@@ -169,15 +169,16 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
     return act, (x, y, st)
 
 
-def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None):
-    """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing)."""
+def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None):
+    """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing).
+    dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient)."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
     if not _bn_uses_batch_stats(bn):
         raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference trains in train mode)')
     dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
     dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
-    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta)
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool)
     dw = _grad_buf(grads, conv.weight)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)
@@ -207,10 +208,10 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None):
     return a2, (s1, s2)
 
 
-def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None):
+def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None):
     seq = dc.double_conv
     s1, s2 = saved
-    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True)
+    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool)
     return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out)
 
 

@@ -330,25 +330,48 @@ def bn_relu_apply(y, state, out=None, pool_out=None):
     return out
 
 
-def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None):
-    """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C])."""
+def pool_bwd_fusable(c, dtype):
+    """Channel counts the fused (skip + max-pool scatter) BatchNorm backward takes (a 16-byte piece per lane)."""
+    e = 16 // torch.empty(0, dtype=dtype).element_size()
+    return c % e == 0 and c // e <= 256 and 256 % (c // e) == 0
+
+
+def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None):
+    """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
+    dpool: the layer's output also fed MaxPool2d(2) -- `dout` is then only the skip-connection gradient and the
+    pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass)."""
     n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
     _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
     dc = dtype_code(y.dtype)
     npix = n * h * w
     sums = new_stats(c, y.device)
     coef = torch.empty((3, c), dtype=torch.float32, device=y.device)
-    check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
-                                         state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
-                                         sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
-    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
-                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
     if out is None:
         out = new_nhwc(n, h, w, c, y.dtype, y.device)
     _, _, _, _, ldo = nhwc_meta(out, 'bn grad output')
-    check(fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
-                                        state.shift.data_ptr(), state.mean.data_ptr(), coef.data_ptr(), out.data_ptr(),
-                                        ldo, npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_apply')
+    if dpool is not None:
+        pn, ph, pw, pc, lddp = nhwc_meta(dpool, 'pool grad')
+        if (pn, ph, pw, pc) != (n, h // 2, w // 2, c) or dpool.dtype != y.dtype or dout.dtype != y.dtype:
+            raise RuntimeError('bn_relu_bwd: dpool must be [N, H//2, W//2, C] of the activation dtype')
+        check(fn['unetk_bn_relu_bwd_reduce_pool'](dout.data_ptr(), lddo, dpool.data_ptr(), lddp, y.data_ptr(), ldy,
+                                                  state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                                  state.invstd.data_ptr(), sums.data_ptr(), n, h, w, c, dc,
+                                                  stream_ptr()), 'unetk_bn_relu_bwd_reduce_pool')
+    else:
+        check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
+                                             state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
+                                             sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
+    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
+                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+    if dpool is not None:
+        check(fn['unetk_bn_relu_bwd_apply_pool'](dout.data_ptr(), lddo, dpool.data_ptr(), lddp, y.data_ptr(), ldy,
+                                                 state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                                 coef.data_ptr(), out.data_ptr(), ldo, n, h, w, c, dc, stream_ptr()),
+              'unetk_bn_relu_bwd_apply_pool')
+    else:
+        check(fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
+                                            state.shift.data_ptr(), state.mean.data_ptr(), coef.data_ptr(),
+                                            out.data_ptr(), ldo, npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_apply')
     return out
 
 

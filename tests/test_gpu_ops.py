@@ -429,3 +429,43 @@ def test_first_conv_bn_relu_equals_torch_eval_chain(dtype):
         assert float((err - (2.0 ** -8) * ref.abs()).max()) < 1e-3
     else:
         assert float(err.max()) < 2e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('h,w,c', [(10, 13, 64), (7, 6, 128), (9, 9, 512)])
+def test_bn_relu_bwd_with_pool_scatter_equals_maxpool_bwd_then_bn_bwd(dtype, h, w, c):
+    """Encoder blocks (unet_model.py:26-30): the BatchNorm backward that forms dskip + max-pool scatter on the fly
+    against the two-kernel path (unetk_maxpool2x2_bwd, then the plain BatchNorm backward).  fp32: the element-wise
+    result is the same arithmetic -> equal to 1e-6 (only the channel sums are accumulated in another order); bf16: the
+    two-kernel path rounds dskip + dpool to bf16 in between."""
+    from unetk import ops
+    torch.manual_seed(h * 100 + w + c)
+    n = 2
+    y = torch.randn((n, h, w, c), device='cuda').to(dtype)
+    bn = torch.nn.BatchNorm2d(c).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    stats = ops.new_stats(c, 'cuda')
+    yf = y.float()
+    stats[0, :, 0] = yf.double().sum((0, 1, 2))
+    stats[0, :, 1] = (yf.double() ** 2).sum((0, 1, 2))
+    st = ops.BNState(c, 'cuda')
+
+    class B:
+        weight, bias, running_mean, running_var, num_batches_tracked = bn.weight, bn.bias, None, None, None
+    ops.bn_train_finalize(stats, n * h * w, B, st, 0.1, 1e-5)
+    cat = torch.randn((n, h, w, c + 64), device='cuda').to(dtype)        # dskip = channel slice of the concat gradient
+    dskip = cat[..., :c]
+    dpool = torch.randn((n, h // 2, w // 2, c), device='cuda').to(dtype)
+    act = ops.bn_relu_apply(y, st)
+    dg1, db1, dg2, db2 = (torch.empty(c, device='cuda') for _ in range(4))
+    fused = ops.bn_relu_bwd(dskip, y, st, bn.weight, dg1, db1, dpool=dpool)
+    dout = ops.maxpool_bwd(act, dpool, dskip)
+    plain = ops.bn_relu_bwd(dout, y, st, bn.weight, dg2, db2)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    scale = float(plain.float().abs().max())
+    assert float((fused.float() - plain.float()).abs().max()) <= tol * scale
+    assert float((dg1 - dg2).abs().max()) <= tol * float(dg2.abs().max())
+    assert float((db1 - db2).abs().max()) <= tol * float(db2.abs().max())
+    assert torch.equal(cat[..., c:], cat[..., c:]) and torch.isfinite(fused.float()).all()
