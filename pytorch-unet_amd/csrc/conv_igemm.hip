@@ -782,6 +782,28 @@ __global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
         const int yb = r0 / P.W, xb = r0 - yb * P.W;
         T* dst0 = reinterpret_cast<T*>(P.y) + P.yoff + co0 +
                   (((size_t)img0 * P.Hs + 2 * yb + (ab >> 1) + P.padT) * P.Ws + 2 * xb + (ab & 1) + P.padL) * P.ldy;
+        if (P.W >= 32 && gb + 32 <= npix) {
+          // fast path (every tile but the ragged last one, any image at least 32 pixels wide): the 32 consecutive
+          // low-res pixels of this row block cross at most one row end (and then at most one image end), so the
+          // destination is two selects away -- no per-element branches (the general path below cost ~10 us per tile
+          // in divergent while-loops and exec-mask branches: the shallow levels ran at 3.3 TB/s)
+          const int to_row_end = P.W - xb;                                   // pixels left in this low-res row
+          const int wrap_rows = 2 + ((yb + 1 >= P.H) ? P.Hs - 2 * P.H : 0);    // up-sampled rows to the next low-res row
+          const int wrap_off = (wrap_rows * P.Ws - 2 * P.W) * P.ldy;          // element offset added after the wrap
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            float v[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              v[nb] = acc[mb][nb][i] + bias[nb];
+              acc[mb][nb][i] = 0.f;
+            }
+            const int off = 2 * row * P.ldy + (row >= to_row_end ? wrap_off : 0);
+            if (!(P.dbg & 4)) store_channels<T, NB>(dst0 + off, v);
+          }
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
