@@ -8,6 +8,8 @@
 // fused BatchNorm statistics, NB-wide channel stores) is the same as conv_igemm.hip.
 //
 // The matching weight gradient uses the transposed problem: rows = k (tap, ci), cols = co, GEMM-K = pixels.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -24,7 +26,7 @@ struct FirstParams {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P) {
+__global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int NB = 2, BN = 64;
   constexpr int STEPS = (36 + 2 * E - 1) / (2 * E);     // bf16: 3 (k < 48), fp32: 5 (k < 40)
@@ -36,27 +38,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  int bid = blockIdx.x;
-  const int nt = bid % P.n_tiles; bid /= P.n_tiles;
-  const int tx = bid % P.tiles_x; bid /= P.tiles_x;
-  const int ty = bid % P.tiles_y;
-  const int img = bid / P.tiles_y;
-  const int y0 = ty * 8, x0 = tx * 32;
+  // a workgroup keeps ONE channel tile and walks spatial tiles grp, grp + ngroups, ...: the weights are turned into
+  // B fragments once per workgroup, not once per 256 pixels (38 400 workgroups of one tile each spent as long in
+  // this prologue's scattered loads as in the tile itself: 0.53 ms for a layer whose HBM floor is 0.23 ms)
+  const int nt = blockIdx.x % P.n_tiles;
+  const int grp = blockIdx.x / P.n_tiles, ngroups = gridDim.x / P.n_tiles;
+  const int spatial = P.N * P.tiles_y * P.tiles_x;
 
-  // ---- image tile + halo -> LDS, converted to T
-  const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
-  for (int p = tid; p < 340; p += 256) {
-    const int hr = p / 34, hc = p - hr * 34;
-    const int yy = y0 + hr - 1, xx = x0 + hc - 1;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-      const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
-      for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
-    }
-    T* dst = reinterpret_cast<T*>(lds_x + p * PXB);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = from_f32<T>(v[c]);
-  }
   // ---- weights -> B fragments (lane (j,h), step s, element e: k = s*2E + h*E + e, channel nt*64 + NB*j + nb)
   for (int i = tid; i < STEPS * NB * 64 * E; i += 256) {
     const int e = i % E;
@@ -71,49 +59,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
     if (tap < 9 && ci < P.Cin) v = P.w[((size_t)co * P.Cin + ci) * 9 + tap];
     reinterpret_cast<T*>(lds_w)[i] = from_f32<T>(v);
   }
-  __syncthreads();
 
-  f32x16 acc[2][NB];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
-
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    uint4 a[2], b[NB];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int row = 2 * wid + mb;
-      if constexpr (sizeof(T) == 2) {
-        const int tapA = 4 * s + 2 * h, tapB = tapA + 1;
-        uint2 lo = {0u, 0u}, hi = {0u, 0u};
-        if (tapA < 9) lo = *reinterpret_cast<const uint2*>(lds_x + ((row + tapA / 3) * 34 + j + tapA % 3) * PXB);
-        if (tapB < 9) hi = *reinterpret_cast<const uint2*>(lds_x + ((row + tapB / 3) * 34 + j + tapB % 3) * PXB);
-        a[mb] = uint4{lo.x, lo.y, hi.x, hi.y};
-      } else {
-        const int tap = 2 * s + h;
-        uint4 v = {0u, 0u, 0u, 0u};
-        if (tap < 9) v = *reinterpret_cast<const uint4*>(lds_x + ((row + tap / 3) * 34 + j + tap % 3) * PXB);
-        a[mb] = v;
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const uint4*>(lds_w + ((s * NB + nb) * 64 + lane) * 16);
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], a[mb], b[nb]);
-  }
-
-  // ---- epilogue (same contract as conv_igemm.hip)
   const int ch0 = nt * BN + NB * j;
-  float ssum[NB], ssq[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
-  T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
   const bool aff = P.aff_scale != nullptr;
   float asc[NB], ash[NB];
 #pragma unroll
@@ -121,43 +68,145 @@ __global__ __launch_bounds__(256, 2) void conv_first_fprop_kernel(FirstParams P)
     asc[nb] = aff ? P.aff_scale[ch0 + nb] : 1.f;
     ash[nb] = aff ? P.aff_shift[ch0 + nb] : 0.f;
   }
+  // BN statistics across this workgroup's tiles: fp32 for bf16 tensors, fp64 for fp32 tensors (conv_igemm.hip)
+  using StatAcc = typename std::conditional<sizeof(T) == 4, double, float>::type;
+  StatAcc tsum[NB], tsq[NB];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int yy = y0 + 2 * wid + mb;
+  for (int nb = 0; nb < NB; ++nb) tsum[nb] = tsq[nb] = 0;
+
+  // the halo pixels of tile t+1 are fetched into registers while tile t is multiplied and stored (the fetch is a
+  // dependent chain of scalar loads from HBM: unhidden, its latency was most of a tile's time)
+  float pre[2][4];
+  auto fetch = [&](int tile) {
+    int bid = tile;
+    const int tx = bid % P.tiles_x; bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int img = bid / P.tiles_y;
+    const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int xx = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (yy < P.H && xx < P.W) {
-        float v[NB];
+    for (int k = 0; k < 2; ++k) {
+      const int p = tid + 256 * k;
+      const int hr = p / 34, hc = p - hr * 34;
+      const int yy = ty * 8 + hr - 1, xx = tx * 32 + hc - 1;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
-          v[nb] = aff ? fmaxf(fmaf(acc[mb][nb][i], asc[nb], ash[nb]), 0.f) : f;
-          ssum[nb] += f;
-          ssq[nb] += f * f;
-        }
-        store_channels<T, NB>(yimg + (size_t)(yy * P.W + xx) * P.ldy + ch0, v);
+      for (int c = 0; c < 4; ++c) pre[k][c] = 0.f;
+      if (p < 340 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+        const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < P.Cin) pre[k][c] = src[c];
       }
     }
+  };
+  if (grp < spatial) fetch(grp);
+
+  for (int tile = grp; tile < spatial; tile += ngroups) {
+    int bid = tile;
+    const int tx = bid % P.tiles_x; bid /= P.tiles_x;
+    const int ty = bid % P.tiles_y;
+    const int img = bid / P.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 32;
+
+    __syncthreads();                                      // every wave is done with the previous tile's pixels
+    // ---- image tile + halo -> LDS, converted to T
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p = tid + 256 * k;
+      if (p < 340) {
+        T* dst = reinterpret_cast<T*>(lds_x + p * PXB);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dst[c] = from_f32<T>(pre[k][c]);
+      }
+    }
+    __syncthreads();
+    if (tile + ngroups < spatial) fetch(tile + ngroups);
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      uint4 a[2], b[NB];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const int row = 2 * wid + mb;
+        if constexpr (sizeof(T) == 2) {
+          const int tapA = 4 * s + 2 * h, tapB = tapA + 1;
+          uint2 lo = {0u, 0u}, hi = {0u, 0u};
+          if (tapA < 9) lo = *reinterpret_cast<const uint2*>(lds_x + ((row + tapA / 3) * 34 + j + tapA % 3) * PXB);
+          if (tapB < 9) hi = *reinterpret_cast<const uint2*>(lds_x + ((row + tapB / 3) * 34 + j + tapB % 3) * PXB);
+          a[mb] = uint4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+          const int tap = 2 * s + h;
+          uint4 v = {0u, 0u, 0u, 0u};
+          if (tap < 9) v = *reinterpret_cast<const uint4*>(lds_x + ((row + tap / 3) * 34 + j + tap % 3) * PXB);
+          a[mb] = v;
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const uint4*>(lds_w + ((s * NB + nb) * 64 + lane) * 16);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], a[mb], b[nb]);
+    }
+
+    // ---- epilogue (same contract as conv_igemm.hip)
+    float ssum[NB], ssq[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    // 64-bit address arithmetic once per row (wave-uniform); an element adds a 32-bit lane offset and a compile-time
+    // multiple of the pixel pitch (as in conv3x3_db_kernel)
+    T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
+    const int lane_off = 4 * h * P.ldy + ch0;
+    const int xl = x0 + 4 * h;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int yy = y0 + 2 * wid + mb;
+      T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ri = (i & 3) + 8 * (i >> 2);
+        if (yy < P.H && xl + ri < P.W) {
+          float v[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
+            v[nb] = aff ? fmaxf(fmaf(acc[mb][nb][i], asc[nb], ash[nb]), 0.f) : f;
+            ssum[nb] += f;
+            ssq[nb] += f * f;
+          }
+          store_channels<T, NB>(rowp + ri * P.ldy + lane_off, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { tsum[nb] += (StatAcc)ssum[nb]; tsq[nb] += (StatAcc)ssq[nb]; }
   }
+
   if (P.stats != nullptr && !aff) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      ssum[nb] += __shfl_xor(ssum[nb], 32, 64);
-      ssq[nb] += __shfl_xor(ssq[nb], 32, 64);
+      tsum[nb] += __shfl_xor(tsum[nb], 32, 64);
+      tsq[nb] += __shfl_xor(tsq[nb], 32, 64);
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
+    StatAcc* red = reinterpret_cast<StatAcc*>(smem);      // [4 waves][BN][2]
     if (h == 0) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        red[(wid * BN + NB * j + nb) * 2 + 0] = ssum[nb];
-        red[(wid * BN + NB * j + nb) * 2 + 1] = ssq[nb];
+        red[(wid * BN + NB * j + nb) * 2 + 0] = tsum[nb];
+        red[(wid * BN + NB * j + nb) * 2 + 1] = tsq[nb];
       }
     }
     __syncthreads();
     if (tid < 2 * BN) {
-      const float v = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+      const StatAcc v = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
       double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
       unsafeAtomicAdd(dst, (double)v);
     }
@@ -432,8 +481,11 @@ static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy
   P.x = x; P.w = w; P.y = y; P.stats = stats; P.aff_scale = scale; P.aff_shift = shift;
   P.N = n; P.H = h; P.W = wd; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.ldy = ldy;
   P.tiles_x = host_cdiv(wd, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = c_out / 64;
-  const long nblk = (long)n * P.tiles_x * P.tiles_y * P.n_tiles;
-  if (nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  const long spatial = (long)n * P.tiles_x * P.tiles_y;
+  if (spatial > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  // ~8 workgroups per CU, each walking its share of the spatial tiles (4 fit a CU at a time)
+  const long groups = spatial < 2048 ? spatial : 2048;
+  const long nblk = groups * P.n_tiles;
   const size_t lds = 340 * 16 + 5 * 2 * 1024;
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(conv_first_fprop_kernel<bf16>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
