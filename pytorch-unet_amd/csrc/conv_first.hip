@@ -447,15 +447,31 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_f32_kernel(FirstWgrad
 }
 
 // dw[co][ci][tap] = sum_split slab[split][ct][k = tap*4+ci][co - ct*64]
-__global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ slab, float* dw, int nsplit, int col_tiles,
-                                               int Cin, int Cout) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Cout * Cin * 9) return;
-  const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
-  const int ct = co >> 6, c = co & 63, k = tap * 4 + ci;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += slab[((size_t)sp * col_tiles + ct) * 4096 + k * 64 + c];
-  dw[idx] = s;
+// one block per (column tile, k row): 64 channels x 4 split groups, coalesced 256-byte rows of the slab, the groups
+// summed in a fixed order through LDS (a thread per output walking all 512 splits serially took 0.16 ms)
+__global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ slab, float* dw,
+                                                                      int nsplit, int col_tiles, int Cin, int Cout) {
+  __shared__ float part[4][64];
+  const int ct = blockIdx.x / 36, k = blockIdx.x % 36;
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int tap = k >> 2, ci = k & 3;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* base = slab + (size_t)ct * 4096 + k * 64 + c;
+  const size_t step = (size_t)col_tiles * 4096;
+  int sp = grp;
+  for (; sp + 12 < nsplit; sp += 16) {
+    s0 += base[(size_t)sp * step];
+    s1 += base[(size_t)(sp + 4) * step];
+    s2 += base[(size_t)(sp + 8) * step];
+    s3 += base[(size_t)(sp + 12) * step];
+  }
+  for (; sp < nsplit; sp += 4) s0 += base[(size_t)sp * step];
+  part[grp][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && ci < Cin) {
+    const int co = ct * 64 + c;
+    if (co < Cout) dw[((size_t)co * Cin + ci) * 9 + tap] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  }
 }
 
 int first_nsplit(int ntiles, int col_tiles) {
@@ -540,8 +556,7 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
                        Q);
   }
   UNETK_CHECK_LAUNCH();
-  const int total = c_out * c_in * 9;
-  hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(P.col_tiles * 36), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, dw, P.nsplit, P.col_tiles, c_in, c_out);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
