@@ -163,6 +163,16 @@ int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool
 int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy,
                                  const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
                                  int lddy, int n, int h, int w, int c, int dtype, void* stream);
+/* ... and for the LAST block's last layer, whose output feeds OutConv (unet_model.py:35, unet_parts.py:74): dout is the
+ * 1x1 convolution's input gradient, dout[p][c] = sum_k dl[p][k] * w[k][c] (dl [npix][n_classes] with pitch lddl, w the
+ * fp32 parameter [n_classes][c]), formed on the fly -- unetk_conv1x1_dgrad and its [npix][c] output are not needed.
+ * UNETK_ERR_SHAPE when n_classes > 4 or c/(16/es) does not divide 256: use unetk_conv1x1_dgrad + the plain calls. */
+int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  double* sums, int64_t npix, int c, int dtype, void* stream);
+int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
+                                 const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
+                                 int lddy, int64_t npix, int c, int dtype, void* stream);
 
 /* ---- MaxPool2d(2): unet_parts.py:34 (aten::max_pool2d), floor mode ---------------------------------------------
  * bwd: dx = (dskip ? dskip : 0) + dpool routed to the first maximum of each window; `dskip` is the gradient the

@@ -524,6 +524,147 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_pool_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------ BN + ReLU backward
+// of the LAST block's second layer, whose output feeds OutConv (unet_model.py:35, unet_parts.py:74): its gradient is
+// the 1x1 convolution's input gradient  dout[p][c] = sum_k dl[p][k] * w[k][c]  -- n_classes multiply-adds per element
+// from a tensor 32x smaller than dout.  Formed on the fly (n_classes <= 4; the fp32 chain of unetk_conv1x1_dgrad,
+// without its rounding to T), it saves that kernel's 1.26 GB write and the two 1.26 GB reads of these passes.
+constexpr int kHeadMax = 4;
+
+// A lane owns FOUR CONSECUTIVE pixels x one 16-byte channel piece per trip.  Their 4 x NCLS logit gradients are
+// contiguous (pitch == NCLS) and come in one or two 16-byte loads -- per-pixel 2-byte loads cost the texture
+// addresser 8x the cycles of the 16-byte load of y and made the fused kernels slower than the plain ones.
+template <typename T, int NCLS>
+struct HeadQuad {
+  static constexpr int E = Vec<T>::E;
+  static constexpr int BYTES = 4 * NCLS * (int)sizeof(T);
+  static constexpr int NV = (BYTES + 15) / 16;
+  static constexpr bool kVector = BYTES % 16 == 0;
+  uint4 yraw[4];
+  float gk[4][NCLS];
+  // q = index of the pixel group; `full` groups have all four pixels inside the tensor
+  __device__ __forceinline__ void load(const T* __restrict__ dl, int lddl, const T* __restrict__ y, int ldy, long q,
+                                       long npix, int c0) {
+    const long p0 = 4 * q;
+    const bool full = p0 + 3 < npix;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long p = p0 + u < npix ? p0 + u : p0;               // clamped; masked by the callers
+      yraw[u] = raw_load(y + p * ldy + c0);
+    }
+    if (kVector && full && lddl == NCLS && (reinterpret_cast<uintptr_t>(dl) & 15) == 0) {
+      uint4 v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const uint4*>(dl + p0 * NCLS + i * (16 / (int)sizeof(T)));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) {
+          constexpr int PER = 16 / (int)sizeof(T);
+          const int e = u * NCLS + k;
+          gk[u][k] = raw_elem<T>(v[e / PER], e % PER);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long p = p0 + u < npix ? p0 + u : p0;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) gk[u][k] = to_f32(dl[p * lddl + k]);
+      }
+    }
+  }
+};
+
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
+    const T* __restrict__ dl, int lddl, const float* __restrict__ w, const T* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, double* sums, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  __shared__ float red[256 * E * 2];
+  const int ppp = C / E;                      // <= 256 and a divisor of 256 (checked by the host)
+  const int lanes = 256 / ppp;
+  const int piece = threadIdx.x % ppp, plane = threadIdx.x / ppp;
+  const int c0 = piece * E;
+  for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float sc[E], sh[E], mu[E], is[E], s1[E], s2[E], wk[NCLS][E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+    s1[i] = s2[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) wk[k][i] = w[k * C + c0 + i];
+  }
+  const long ngroups = (npix + 3) / 4;
+  for (long q = (long)blockIdx.x * lanes + plane; q < ngroups; q += (long)gridDim.x * lanes) {
+    HeadQuad<T, NCLS> Q;
+    Q.load(dl, lddl, y, ldy, q, npix, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = 4 * q + u < npix;
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float v = raw_elem<T>(Q.yraw[u], i);
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) g = fmaf(Q.gk[u][k], wk[k][i], g);
+        const float dz = (live && fmaf(v, sc[i], sh[i]) > 0.f) ? g : 0.f;
+        s1[i] += dz;
+        s2[i] += dz * (v - mu[i]) * is[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], s2[i]);
+  }
+  __syncthreads();
+  double* dst = sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C * 2;
+  for (int i = threadIdx.x; i < C * 2; i += 256) unsafeAtomicAdd(dst + i, (double)red[i]);
+}
+
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_head_kernel(
+    const T* __restrict__ dl, int lddl, const float* __restrict__ w, const T* __restrict__ y, int ldy,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ coef, T* __restrict__ dy, int lddy, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  const int ppp = C / E;
+  const int lanes = 256 / ppp;
+  const int c0 = (threadIdx.x % ppp) * E;
+  const int plane = threadIdx.x / ppp;
+  float sc[E], sh[E], mu[E], ka[E], kb[E], kc[E], wk[NCLS][E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i];
+    ka[i] = coef[c0 + i]; kb[i] = coef[C + c0 + i]; kc[i] = coef[2 * C + c0 + i];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) wk[k][i] = w[k * C + c0 + i];
+  }
+  const long ngroups = (npix + 3) / 4;
+  for (long q = (long)blockIdx.x * lanes + plane; q < ngroups; q += (long)gridDim.x * lanes) {
+    HeadQuad<T, NCLS> Q;
+    Q.load(dl, lddl, y, ldy, q, npix, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (4 * q + u >= npix) break;
+      float o[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float v = raw_elem<T>(Q.yraw[u], i);
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) g = fmaf(Q.gk[u][k], wk[k][i], g);
+        const float dz = fmaf(v, sc[i], sh[i]) > 0.f ? g : 0.f;
+        o[i] = ka[i] * dz - kb[i] - kc[i] * (v - mu[i]);
+      }
+      Vec<T>::store(dy + (4 * q + u) * lddy + c0, o);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ MaxPool2d(2)
 // unet_parts.py:34: k2 s2, floor mode -- an odd last row/column is dropped.
 template <typename T>
@@ -930,6 +1071,63 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
                          (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy, lddy, (long)npix, c);
   });
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+static int head_bwd_check(const void* dl, int lddl, const float* w, int ncls, const void* y, int ldy, int64_t npix,
+                          int c, int dtype) {
+  if (!dl || !w || !y || npix <= 0 || c <= 0) return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  if (ncls < 1 || ncls > kHeadMax || lddl < ncls) return UNETK_ERR_SHAPE;   // more classes: conv1x1_dgrad + plain passes
+  if (c % E || c / E > 256 || 256 % (c / E) || ldy < c) return UNETK_ERR_SHAPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if ((ldy * es) % 16 || (reinterpret_cast<uintptr_t>(y) & 15)) return UNETK_ERR_ALIGN;
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  double* sums, int64_t npix, int c, int dtype, void* stream) {
+  if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
+  if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 1024);
+#define HEAD_REDUCE(NC)                                                                                              \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_head_kernel<T, NC>), dim3(grid), dim3(256), 0,            \
+                                       (hipStream_t)stream, (const T*)dl, lddl, w, (const T*)y, ldy, scale, shift,   \
+                                       mean, invstd, sums, (long)npix, c))
+  switch (n_classes) {
+    case 1: HEAD_REDUCE(1); break;
+    case 2: HEAD_REDUCE(2); break;
+    case 3: HEAD_REDUCE(3); break;
+    default: HEAD_REDUCE(4); break;
+  }
+#undef HEAD_REDUCE
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
+                                 const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
+                                 int lddy, int64_t npix, int c, int dtype, void* stream) {
+  if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
+  if (!scale || !shift || !mean || !coef) return UNETK_ERR_ARG;
+  if (int e = check_act(dy, lddy, c, dtype)) return e;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 256 * EW_BWD_MUL);
+#define HEAD_APPLY(NC)                                                                                               \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_head_kernel<T, NC>), dim3(grid), dim3(256), 0,             \
+                                       (hipStream_t)stream, (const T*)dl, lddl, w, (const T*)y, ldy, scale, shift,   \
+                                       mean, coef, (T*)dy, lddy, (long)npix, c))
+  switch (n_classes) {
+    case 1: HEAD_APPLY(1); break;
+    case 2: HEAD_APPLY(2); break;
+    case 3: HEAD_APPLY(3); break;
+    default: HEAD_APPLY(4); break;
+  }
+#undef HEAD_APPLY
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

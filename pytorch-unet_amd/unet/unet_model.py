@@ -83,12 +83,13 @@ class _UNetImpl:
             if ready is not None:
                 ready([p for p in params if p is not None], grads)
 
-        d = blocks.head_bwd(net.outc.conv, saved['head'], dlogits, grads, True)
+        # OutConv's input gradient is formed inside the BatchNorm backward of up4's last layer where it can be
+        d, dhead = blocks.head_bwd(net.outc.conv, saved['head'], dlogits, grads, True, fuse_dx=True)
         done([net.outc.conv.weight, net.outc.conv.bias])
         dcats = [None] * 4
         for k in (3, 2, 1, 0):
             up = ups[k]
-            dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True)
+            dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None)
             dcats[k] = dcat
             d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True)
             done(blocks.up_params(up))

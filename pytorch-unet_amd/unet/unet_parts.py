@@ -119,7 +119,7 @@ class _OutConvImpl:
         return blocks.head_fwd(self.conv, x, self.dtype)
 
     def bwd(self, saved, dout, grads, needs):
-        return (blocks.head_bwd(self.conv, saved, dout, grads, needs[0]),)
+        return (blocks.head_bwd(self.conv, saved, dout, grads, needs[0])[0],)
 
 
 class OutConv(nn.Module):

@@ -169,16 +169,17 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
     return act, (x, y, st)
 
 
-def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None):
+def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None):
     """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing).
-    dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient)."""
+    dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient).
+    dhead: (dlogits, OutConv weight) when OutConv consumed this layer's output (`dact` is then None)."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
     if not _bn_uses_batch_stats(bn):
         raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference trains in train mode)')
     dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
     dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
-    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool)
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead)
     dw = _grad_buf(grads, conv.weight)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)
@@ -208,10 +209,10 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None):
     return a2, (s1, s2)
 
 
-def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None):
+def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None):
     seq = dc.double_conv
     s1, s2 = saved
-    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool)
+    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead)
     return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out)
 
 
@@ -281,8 +282,14 @@ def head_fwd(conv, x, dtype):
     return ops.conv1x1_fwd(x, w, _f32c(conv.bias), conv.out_channels), (x, w)
 
 
-def head_bwd(conv, saved, dl, grads, need_dx=True):
+def head_bwd(conv, saved, dl, grads, need_dx=True, fuse_dx=False):
+    """fuse_dx: return (dlogits, weight) instead of the input gradient when the consumer's BatchNorm backward can form
+    it on the fly (ops.head_bwd_fusable) -- the caller passes that pair on as `dhead`."""
     x, w = saved
     if dl.dtype != x.dtype:
         dl = dl.to(x.dtype)
-    return ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), need_dx)
+    n_classes, c = conv.out_channels, conv.in_channels
+    if need_dx and fuse_dx and ops.head_bwd_fusable(c, n_classes, x.dtype):
+        ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), False)
+        return None, (dl, w.reshape(n_classes, c))
+    return ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), need_dx), None

@@ -336,10 +336,19 @@ def pool_bwd_fusable(c, dtype):
     return c % e == 0 and c // e <= 256 and 256 % (c // e) == 0
 
 
-def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None):
+def head_bwd_fusable(c, n_classes, dtype):
+    """OutConv shapes whose input gradient the BatchNorm backward kernels can form on the fly."""
+    return n_classes <= 4 and pool_bwd_fusable(c, dtype)
+
+
+def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None):
     """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
     dpool: the layer's output also fed MaxPool2d(2) -- `dout` is then only the skip-connection gradient and the
-    pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass)."""
+    pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass).
+    dhead: (dlogits [N,H,W,n_classes], OutConv weight fp32 [n_classes, C]) -- the layer's output fed OutConv; `dout`
+    is None and the 1x1 convolution's input gradient is formed on the fly."""
+    if dhead is not None:
+        return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out)
     n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
     _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
     dc = dtype_code(y.dtype)
@@ -372,6 +381,32 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None):
         check(fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
                                             state.shift.data_ptr(), state.mean.data_ptr(), coef.data_ptr(),
                                             out.data_ptr(), ldo, npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_apply')
+    return out
+
+
+def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out):
+    n, h, w, c, ldy = nhwc_meta(y, 'bn saved input')
+    dn, dh, dw_, ncls, lddl = nhwc_meta(dl, 'head grad')
+    if (dn, dh, dw_) != (n, h, w) or dl.dtype != y.dtype or w_head.dtype != torch.float32 or w_head.numel() != ncls * c \
+            or not w_head.is_contiguous():
+        raise RuntimeError('bn_relu_bwd: dlogits / OutConv weight do not match the layer')
+    dc = dtype_code(y.dtype)
+    npix = n * h * w
+    sums = new_stats(c, y.device)
+    coef = torch.empty((3, c), dtype=torch.float32, device=y.device)
+    if out is None:
+        out = new_nhwc(n, h, w, c, y.dtype, y.device)
+    _, _, _, _, ldo = nhwc_meta(out, 'bn grad output')
+    check(fn['unetk_bn_relu_bwd_reduce_head'](dl.data_ptr(), lddl, w_head.data_ptr(), ncls, y.data_ptr(), ldy,
+                                              state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                              state.invstd.data_ptr(), sums.data_ptr(), npix, c, dc, stream_ptr()),
+          'unetk_bn_relu_bwd_reduce_head')
+    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
+                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+    check(fn['unetk_bn_relu_bwd_apply_head'](dl.data_ptr(), lddl, w_head.data_ptr(), ncls, y.data_ptr(), ldy,
+                                             state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                             coef.data_ptr(), out.data_ptr(), ldo, npix, c, dc, stream_ptr()),
+          'unetk_bn_relu_bwd_apply_head')
     return out
 
 

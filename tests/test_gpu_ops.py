@@ -469,3 +469,35 @@ def test_bn_relu_bwd_with_pool_scatter_equals_maxpool_bwd_then_bn_bwd(dtype, h, 
     assert float((dg1 - dg2).abs().max()) <= tol * float(dg2.abs().max())
     assert float((db1 - db2).abs().max()) <= tol * float(db2.abs().max())
     assert torch.equal(cat[..., c:], cat[..., c:]) and torch.isfinite(fused.float()).all()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ncls', [1, 2, 4])
+def test_bn_relu_bwd_with_head_gradient_equals_conv1x1_dgrad_then_bn_bwd(dtype, ncls):
+    """Last block (unet_model.py:35): the BatchNorm backward that forms OutConv's input gradient on the fly against
+    unetk_conv1x1_dgrad followed by the plain BatchNorm backward.  fp32: same fp32 chain -> 1e-5; bf16: the two-kernel
+    path rounds the input gradient to bf16 in between."""
+    from unetk import ops
+    torch.manual_seed(ncls)
+    n, h, w, c = 2, 11, 17, 64
+    y = torch.randn((n, h, w, c), device='cuda').to(dtype)
+    gamma = torch.rand(c, device='cuda') + 0.5
+    stats = ops.new_stats(c, 'cuda')
+    stats[0, :, 0] = y.double().sum((0, 1, 2))
+    stats[0, :, 1] = (y.double() ** 2).sum((0, 1, 2))
+    st = ops.BNState(c, 'cuda')
+
+    class B:
+        weight, bias, running_mean, running_var, num_batches_tracked = gamma, torch.zeros(c, device='cuda'), None, None, None
+    ops.bn_train_finalize(stats, n * h * w, B, st, 0.1, 1e-5)
+    dl = (torch.randn((n, h, w, ncls), device='cuda') * 0.1).to(dtype)
+    wh = torch.randn((ncls, c), device='cuda') * 0.2
+    x = torch.randn((n, h, w, c), device='cuda').to(dtype)
+    dg1, db1, dg2, db2 = (torch.empty(c, device='cuda') for _ in range(4))
+    fused = ops.bn_relu_bwd(None, y, st, gamma, dg1, db1, dhead=(dl, wh))
+    dx = ops.conv1x1_bwd(x, dl, wh, torch.empty((ncls, c, 1, 1), device='cuda'), torch.empty(ncls, device='cuda'), True)
+    plain = ops.bn_relu_bwd(dx, y, st, gamma, dg2, db2)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert float((fused.float() - plain.float()).abs().max()) <= tol * float(plain.float().abs().max())
+    assert float((dg1 - dg2).abs().max()) <= tol * float(dg2.abs().max())
+    assert float((db1 - db2).abs().max()) <= tol * float(db2.abs().max())
