@@ -169,7 +169,12 @@ int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool,
  * UNETK_ERR_SHAPE when n_classes > 4 or c/(16/es) does not divide 256: use unetk_conv1x1_dgrad + the plain calls. */
 int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
-                                  double* sums, int64_t npix, int c, int dtype, void* stream);
+                                  double* sums, double* head_sums, int64_t npix, int c, int dtype, void* stream);
+/* head_sums != NULL (UNETK_STAT_REPLICAS * n_classes * (c+1) doubles, zeroed by the caller): the reduce pass also
+ * accumulates OutConv's own weight/bias gradient -- its input is this layer's activation relu(bn(y)), which the pass
+ * recomputes anyway -- and unetk_conv1x1_wgrad_finalize turns the replicas into dw [n_classes][c] and db [n_classes]
+ * (autograd of unet_parts.py:74; replaces unetk_conv1x1_wgrad and its pass over the activation). */
+int unetk_conv1x1_wgrad_finalize(const double* head_sums, float* dw, float* db, int c_in, int n_classes, void* stream);
 int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
                                  const float* scale, const float* shift, const float* mean, const float* coef, void* dy,
                                  int lddy, int64_t npix, int c, int dtype, void* stream);

@@ -579,23 +579,31 @@ template <typename T, int NCLS>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
     const T* __restrict__ dl, int lddl, const float* __restrict__ w, const T* __restrict__ y, int ldy,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, double* sums, long npix, int C) {
+    const float* __restrict__ invstd, double* sums, double* head_sums, long npix, int C) {
   constexpr int E = Vec<T>::E;
   __shared__ float red[256 * E * 2];
+  __shared__ float hred[NCLS * (256 * E + 1)];
   const int ppp = C / E;                      // <= 256 and a divisor of 256 (checked by the host)
   const int lanes = 256 / ppp;
   const int piece = threadIdx.x % ppp, plane = threadIdx.x / ppp;
   const int c0 = piece * E;
   for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < NCLS * (C + 1); i += 256) hred[i] = 0.f;
   __syncthreads();
   float sc[E], sh[E], mu[E], is[E], s1[E], s2[E], wk[NCLS][E];
+  // head_sums != NULL: OutConv's weight / bias gradient as a by-product -- its input IS this layer's activation
+  // relu(bn(y)) (rounded to T as the forward stored it), which this pass recomputes for the mask anyway:
+  //   dw[k][c] = sum_p dl[p][k] * a[p][c],  db[k] = sum_p dl[p][k]           (no pass over the activation)
+  float hw[NCLS][E], hb[NCLS];
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
     s1[i] = s2[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) wk[k][i] = w[k * C + c0 + i];
+    for (int k = 0; k < NCLS; ++k) { wk[k][i] = w[k * C + c0 + i]; hw[k][i] = 0.f; }
   }
+#pragma unroll
+  for (int k = 0; k < NCLS; ++k) hb[k] = 0.f;
   const long ngroups = (npix + 3) / 4;
   for (long q = (long)blockIdx.x * lanes + plane; q < ngroups; q += (long)gridDim.x * lanes) {
     HeadQuad<T, NCLS> Q;
@@ -604,12 +612,22 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
     for (int u = 0; u < 4; ++u) {
       const bool live = 4 * q + u < npix;
 #pragma unroll
+      for (int k = 0; k < NCLS; ++k) {
+        if (!live) Q.gk[u][k] = 0.f;
+        hb[k] += Q.gk[u][k];
+      }
+#pragma unroll
       for (int i = 0; i < E; ++i) {
         const float v = raw_elem<T>(Q.yraw[u], i);
+        const float pre = fmaf(v, sc[i], sh[i]);
+        const float a = to_f32(from_f32<T>(fmaxf(pre, 0.f)));
         float g = 0.f;
 #pragma unroll
-        for (int k = 0; k < NCLS; ++k) g = fmaf(Q.gk[u][k], wk[k][i], g);
-        const float dz = (live && fmaf(v, sc[i], sh[i]) > 0.f) ? g : 0.f;
+        for (int k = 0; k < NCLS; ++k) {
+          g = fmaf(Q.gk[u][k], wk[k][i], g);
+          hw[k][i] = fmaf(Q.gk[u][k], a, hw[k][i]);
+        }
+        const float dz = pre > 0.f ? g : 0.f;
         s1[i] += dz;
         s2[i] += dz * (v - mu[i]) * is[i];
       }
@@ -620,9 +638,33 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
     atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
     atomicAdd(&red[(piece * E + i) * 2 + 1], s2[i]);
   }
+  if (head_sums != nullptr) {
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) atomicAdd(&hred[k * (C + 1) + c0 + i], hw[k][i]);
+      if (piece == 0) atomicAdd(&hred[k * (C + 1) + C], hb[k]);
+    }
+  }
   __syncthreads();
   double* dst = sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C * 2;
   for (int i = threadIdx.x; i < C * 2; i += 256) unsafeAtomicAdd(dst + i, (double)red[i]);
+  if (head_sums != nullptr) {
+    double* hd = head_sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * NCLS * (C + 1);
+    for (int i = threadIdx.x; i < NCLS * (C + 1); i += 256) unsafeAtomicAdd(hd + i, (double)hred[i]);
+  }
+}
+
+// dw [n_classes][C] and db [n_classes] of OutConv from the replicas of the by-product above
+__global__ void head_wgrad_finalize_kernel(const double* __restrict__ head_sums, float* __restrict__ dw,
+                                           float* __restrict__ db, int C, int ncls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncls * (C + 1)) return;
+  double s = 0;
+  for (int r = 0; r < UNETK_STAT_REPLICAS; ++r) s += head_sums[(size_t)r * ncls * (C + 1) + i];
+  const int k = i / (C + 1), c = i - k * (C + 1);
+  if (c < C) dw[k * C + c] = (float)s;
+  else if (db) db[k] = (float)s;
 }
 
 template <typename T, int NCLS>
@@ -1089,7 +1131,7 @@ static int head_bwd_check(const void* dl, int lddl, const float* w, int ncls, co
 
 int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int n_classes, const void* y, int ldy,
                                   const float* scale, const float* shift, const float* mean, const float* invstd,
-                                  double* sums, int64_t npix, int c, int dtype, void* stream) {
+                                  double* sums, double* head_sums, int64_t npix, int c, int dtype, void* stream) {
   if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
   if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
   const int E = dtype == UNETK_BF16 ? 8 : 4;
@@ -1097,7 +1139,7 @@ int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int 
 #define HEAD_REDUCE(NC)                                                                                              \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_head_kernel<T, NC>), dim3(grid), dim3(256), 0,            \
                                        (hipStream_t)stream, (const T*)dl, lddl, w, (const T*)y, ldy, scale, shift,   \
-                                       mean, invstd, sums, (long)npix, c))
+                                       mean, invstd, sums, head_sums, (long)npix, c))
   switch (n_classes) {
     case 1: HEAD_REDUCE(1); break;
     case 2: HEAD_REDUCE(2); break;
@@ -1105,6 +1147,15 @@ int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int 
     default: HEAD_REDUCE(4); break;
   }
 #undef HEAD_REDUCE
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_conv1x1_wgrad_finalize(const double* head_sums, float* dw, float* db, int c_in, int n_classes, void* stream) {
+  if (!head_sums || !dw || c_in <= 0 || n_classes < 1 || n_classes > kHeadMax) return UNETK_ERR_ARG;
+  const int total = n_classes * (c_in + 1);
+  hipLaunchKernelGGL(head_wgrad_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, head_sums,
+                     dw, db, c_in, n_classes);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -76,8 +76,9 @@ class _UNetImpl:
         init = getattr(net, '_initial_grads', None)
         if init is not None:
             grads.update(init())          # gradients land in one flat, bucket-ordered buffer (unetk.ddp)
+        # per-channel accumulators of the 18 BatchNorm backward passes + OutConv's gradient replicas (<= 4 x 65 values)
         ops.begin_stats_arena(dlogits.device,
-                              sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)))
+                              sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)) + 160)
 
         def done(params):
             if ready is not None:
@@ -85,11 +86,14 @@ class _UNetImpl:
 
         # OutConv's input gradient is formed inside the BatchNorm backward of up4's last layer where it can be
         d, dhead = blocks.head_bwd(net.outc.conv, saved['head'], dlogits, grads, True, fuse_dx=True)
-        done([net.outc.conv.weight, net.outc.conv.bias])
+        if dhead is None:
+            done([net.outc.conv.weight, net.outc.conv.bias])
         dcats = [None] * 4
         for k in (3, 2, 1, 0):
             up = ups[k]
             dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None)
+            if k == 3 and dhead is not None:      # OutConv's gradients came out of up4's BatchNorm backward
+                done([net.outc.conv.weight, net.outc.conv.bias])
             dcats[k] = dcat
             d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True)
             done(blocks.up_params(up))

@@ -283,13 +283,14 @@ def head_fwd(conv, x, dtype):
 
 
 def head_bwd(conv, saved, dl, grads, need_dx=True, fuse_dx=False):
-    """fuse_dx: return (dlogits, weight) instead of the input gradient when the consumer's BatchNorm backward can form
-    it on the fly (ops.head_bwd_fusable) -- the caller passes that pair on as `dhead`."""
+    """Returns (input gradient, None), or with fuse_dx -- when the consumer's BatchNorm backward can form the input
+    gradient and OutConv's own weight/bias gradient on the fly (ops.head_bwd_fusable) -- (None, dhead): nothing is
+    launched here and the caller passes `dhead` on to double_conv_bwd of the block that fed OutConv."""
     x, w = saved
     if dl.dtype != x.dtype:
         dl = dl.to(x.dtype)
     n_classes, c = conv.out_channels, conv.in_channels
+    dw, db = _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias)
     if need_dx and fuse_dx and ops.head_bwd_fusable(c, n_classes, x.dtype):
-        ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), False)
-        return None, (dl, w.reshape(n_classes, c))
-    return ops.conv1x1_bwd(x, dl, w, _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias), need_dx), None
+        return None, (dl, w.reshape(n_classes, c), dw, db)
+    return ops.conv1x1_bwd(x, dl, w, dw, db, need_dx), None

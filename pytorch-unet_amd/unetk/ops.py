@@ -345,10 +345,11 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
     """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
     dpool: the layer's output also fed MaxPool2d(2) -- `dout` is then only the skip-connection gradient and the
     pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass).
-    dhead: (dlogits [N,H,W,n_classes], OutConv weight fp32 [n_classes, C]) -- the layer's output fed OutConv; `dout`
-    is None and the 1x1 convolution's input gradient is formed on the fly."""
+    dhead: (dlogits [N,H,W,n_classes], OutConv weight fp32 [n_classes, C], dw, db) -- the layer's output fed OutConv;
+    `dout` is None and the 1x1 convolution's input gradient is formed on the fly; dw/db (fp32 gradient buffers of
+    OutConv's weight [n_classes,C,1,1] and bias, or None) are filled as a by-product of the reduction pass."""
     if dhead is not None:
-        return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out)
+        return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out, *dhead[2:])
     n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
     _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
     dc = dtype_code(y.dtype)
@@ -384,7 +385,12 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
     return out
 
 
-def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out):
+def new_zero_doubles(n, device):
+    t = _ARENA.take(n, device)
+    return t if t is not None else torch.zeros(n, dtype=torch.float64, device=device)
+
+
+def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out, dw_head=None, db_head=None):
     n, h, w, c, ldy = nhwc_meta(y, 'bn saved input')
     dn, dh, dw_, ncls, lddl = nhwc_meta(dl, 'head grad')
     if (dn, dh, dw_) != (n, h, w) or dl.dtype != y.dtype or w_head.dtype != torch.float32 or w_head.numel() != ncls * c \
@@ -397,10 +403,18 @@ def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out):
     if out is None:
         out = new_nhwc(n, h, w, c, y.dtype, y.device)
     _, _, _, _, ldo = nhwc_meta(out, 'bn grad output')
+    hsums = None
+    if dw_head is not None:
+        if dw_head.dtype != torch.float32 or dw_head.numel() != ncls * c or not dw_head.is_contiguous():
+            raise RuntimeError('bn_relu_bwd: OutConv weight-gradient buffer must be contiguous fp32 [n_classes, C, 1, 1]')
+        hsums = new_zero_doubles(nat.STAT_REPLICAS * ncls * (c + 1), y.device)
     check(fn['unetk_bn_relu_bwd_reduce_head'](dl.data_ptr(), lddl, w_head.data_ptr(), ncls, y.data_ptr(), ldy,
                                               state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
-                                              state.invstd.data_ptr(), sums.data_ptr(), npix, c, dc, stream_ptr()),
-          'unetk_bn_relu_bwd_reduce_head')
+                                              state.invstd.data_ptr(), sums.data_ptr(), _ptr(hsums), npix, c, dc,
+                                              stream_ptr()), 'unetk_bn_relu_bwd_reduce_head')
+    if hsums is not None:
+        check(fn['unetk_conv1x1_wgrad_finalize'](hsums.data_ptr(), dw_head.data_ptr(), _ptr(db_head), c, ncls,
+                                                 stream_ptr()), 'unetk_conv1x1_wgrad_finalize')
     check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
                                            _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
     check(fn['unetk_bn_relu_bwd_apply_head'](dl.data_ptr(), lddl, w_head.data_ptr(), ncls, y.data_ptr(), ldy,

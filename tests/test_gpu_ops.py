@@ -494,9 +494,15 @@ def test_bn_relu_bwd_with_head_gradient_equals_conv1x1_dgrad_then_bn_bwd(dtype, 
     wh = torch.randn((ncls, c), device='cuda') * 0.2
     x = torch.randn((n, h, w, c), device='cuda').to(dtype)
     dg1, db1, dg2, db2 = (torch.empty(c, device='cuda') for _ in range(4))
-    fused = ops.bn_relu_bwd(None, y, st, gamma, dg1, db1, dhead=(dl, wh))
-    dx = ops.conv1x1_bwd(x, dl, wh, torch.empty((ncls, c, 1, 1), device='cuda'), torch.empty(ncls, device='cuda'), True)
+    # OutConv's own gradients come out of the same pass: its input is this layer's activation
+    x = ops.bn_relu_apply(y, st)
+    hw1, hb1 = torch.empty((ncls, c, 1, 1), device='cuda'), torch.empty(ncls, device='cuda')
+    hw2, hb2 = torch.empty((ncls, c, 1, 1), device='cuda'), torch.empty(ncls, device='cuda')
+    fused = ops.bn_relu_bwd(None, y, st, gamma, dg1, db1, dhead=(dl, wh, hw1, hb1))
+    dx = ops.conv1x1_bwd(x, dl, wh, hw2, hb2, True)
     plain = ops.bn_relu_bwd(dx, y, st, gamma, dg2, db2)
+    assert float((hw1 - hw2).abs().max()) <= 1e-4 * float(hw2.abs().max()) + 1e-6
+    assert float((hb1 - hb2).abs().max()) <= 1e-4 * float(hb2.abs().max()) + 1e-6
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     assert float((fused.float() - plain.float()).abs().max()) <= tol * float(plain.float().abs().max())
     assert float((dg1 - dg2).abs().max()) <= tol * float(dg2.abs().max())
