@@ -143,6 +143,13 @@ int unetk_bn_relu_apply(const void* y, int ldy, const float* scale, const float*
  * Returns UNETK_ERR_SHAPE when c/(16/es) does not divide 256 (use bn_relu_apply + maxpool2x2_fwd then). */
 int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
                              void* pool, int ldp, int n, int h, int w, int c, int dtype, void* stream);
+/* The same apply for the LAST block's last layer, which feeds OutConv (unet_model.py:35, unet_parts.py:74): besides
+ * out = relu(y*scale+shift) it emits logits[p][k] = sum_c out[p][c] * w[k][c] + bias[k] (w the fp32 parameter
+ * [n_classes][c]; the arithmetic of unetk_conv1x1_fwd on the rounded activation) -- no pass over the activation.
+ * UNETK_ERR_SHAPE when n_classes > 4 or c/(16/es) is not a power of two <= 64: use bn_relu_apply + conv1x1_fwd. */
+int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                             const float* w, const float* bias, int n_classes, void* logits, int ldl, int64_t npix,
+                             int c, int dtype, void* stream);
 /* backward through ReLU and train-mode BN: reduce (sums [REPLICAS][c][2] doubles, zeroed by the caller) ->
  * finalize (dgamma, dbeta, coef [3][c]) -> apply (dy = coef0*dz - coef1 - coef2*(y-mean)). */
 int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, const float* scale, const float* shift,

@@ -575,6 +575,87 @@ struct HeadQuad {
   }
 };
 
+// Forward of the same pair (unet_parts.py:20-21 then :74): BatchNorm + ReLU apply of the last block's last layer that
+// also emits OutConv's logits -- the activation is in registers, so the 1x1 convolution costs n_classes dot products
+// per pixel (8 channels per lane, then an xor-shuffle sum over the pixel's lanes: the arithmetic of
+// conv1x1_fwd_kernel on the rounded activation) and no pass over the activation.
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ out,
+                                                                 int ldo, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, T* __restrict__ logits,
+                                                                 int ldl, long npix, int C) {
+  constexpr int E = Vec<T>::E;
+  constexpr int PER = 16 / (int)sizeof(T);
+  constexpr int BYTES = 4 * NCLS * (int)sizeof(T);
+  const int ppp = C / E;                      // a power of two <= 64: a pixel's lanes sit in one wave
+  const int lanes = 256 / ppp;
+  const int piece = threadIdx.x % ppp, plane = threadIdx.x / ppp;
+  const int c0 = piece * E;
+  float sc[E], sh[E], wk[NCLS][E], bk[NCLS];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) wk[k][i] = w[k * C + c0 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < NCLS; ++k) bk[k] = bias[k];
+  const bool vec_ok = BYTES % 16 == 0 && ldl == NCLS && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+  const long ngroups = (npix + 3) / 4;
+  // every lane of a wave runs the same number of trips (the shuffles below need the pixel's lanes converged)
+  const long trips = (ngroups + (long)gridDim.x * lanes - 1) / ((long)gridDim.x * lanes);
+  for (long t = 0; t < trips; ++t) {
+    const long q = (t * gridDim.x + blockIdx.x) * lanes + plane;
+    const long p0 = 4 * q;
+    float acc[4][NCLS];
+    uint4 raws[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raws[u] = raw_load(y + (p0 + u < npix ? p0 + u : 0) * ldy + c0);   // all in flight
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = p0 + u < npix;
+      const long p = live ? p0 + u : 0;
+      const uint4 raw = raws[u];
+      float a[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaf(raw_elem<T>(raw, i), sc[i], sh[i]), 0.f);
+      if (live) Vec<T>::store(out + p * ldo + c0, a);
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < E; ++i) d = fmaf(to_f32(from_f32<T>(a[i])), wk[k][i], d);
+        acc[u][k] = d;
+      }
+    }
+    for (int o = ppp >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) acc[u][k] += __shfl_xor(acc[u][k], o, 64);
+    if (piece == 0 && p0 < npix) {
+      if (vec_ok && p0 + 3 < npix) {
+        alignas(16) T tmp[((4 * NCLS + PER - 1) / PER) * PER];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < NCLS; ++k) tmp[u * NCLS + k] = from_f32<T>(acc[u][k] + bk[k]);
+#pragma unroll
+        for (int i = 0; i < BYTES / 16; ++i)
+          *reinterpret_cast<uint4*>(logits + p0 * NCLS + i * PER) = *reinterpret_cast<const uint4*>(tmp + i * PER);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (p0 + u < npix)
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) logits[(p0 + u) * ldl + k] = from_f32<T>(acc[u][k] + bk[k]);
+      }
+    }
+  }
+}
+
 template <typename T, int NCLS>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
     const T* __restrict__ dl, int lddl, const float* __restrict__ w, const T* __restrict__ y, int ldy,
@@ -1113,6 +1194,32 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
       hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_grid(npix * ppp)), dim3(256), 0, (hipStream_t)stream,
                          (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, coef, (T*)dy, lddy, (long)npix, c);
   });
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
+                             const float* w, const float* bias, int n_classes, void* logits, int ldl, int64_t npix,
+                             int c, int dtype, void* stream) {
+  if (!y || !scale || !shift || !out || !w || !bias || !logits || npix <= 0) return UNETK_ERR_ARG;
+  if (int e = check_act(y, ldy, c, dtype)) return e;
+  if (int e = check_act(out, ldo, c, dtype)) return e;
+  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int ppp = c / E;
+  // a pixel's lanes must share a wave for the shuffle sum: ppp a power of two <= 64
+  if (n_classes < 1 || n_classes > kHeadMax || ldl < n_classes || ppp > 64 || (ppp & (ppp - 1))) return UNETK_ERR_SHAPE;
+  const int grid = ew_grid((npix + 3) / 4, 256 / ppp, 256 * EW_APPLY_MUL);
+#define HEAD_FWD(NC)                                                                                                \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_apply_head_kernel<T, NC>), dim3(grid), dim3(256), 0,                 \
+                                       (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, w, bias,   \
+                                       (T*)logits, ldl, (long)npix, c))
+  switch (n_classes) {
+    case 1: HEAD_FWD(1); break;
+    case 2: HEAD_FWD(2); break;
+    case 3: HEAD_FWD(3); break;
+    default: HEAD_FWD(4); break;
+  }
+#undef HEAD_FWD
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

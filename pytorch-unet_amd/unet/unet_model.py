@@ -59,10 +59,15 @@ class _UNetImpl:
         for k, up in enumerate(ups):
             cat, c_skip = skips[3 - k]
             saved['up'].append(blocks.up_into_cat(up.up, cur, cat, c_skip, dt))
-            cur, s = blocks.double_conv_fwd(up.conv, cat, dt)
+            # the last block's BatchNorm+ReLU kernel also emits OutConv's logits where it can
+            head = {'conv': net.outc.conv} if k == 3 else None
+            cur, s = blocks.double_conv_fwd(up.conv, cat, dt, head=head)
             saved['dec'].append(s)
             saved['cats'].append(c_skip)
-        logits, hs = blocks.head_fwd(net.outc.conv, cur, dt)
+        if head is not None and 'logits' in head:
+            logits, hs = head['logits'], head['saved']
+        else:
+            logits, hs = blocks.head_fwd(net.outc.conv, cur, dt)
         saved['head'] = hs
         return logits, saved
 

@@ -119,9 +119,11 @@ def _check_bn(bn):
         raise RuntimeError('BatchNorm parameters must be fp32 (keep the model in fp32 and use autocast for bf16)')
 
 
-def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
+def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     """One conv3x3 -> BN -> ReLU.  x: NHWC view (fp32 image for the first layer, else `dtype`).
-    Returns (activation, saved) with saved = (x, y, state)."""
+    Returns (activation, saved) with saved = (x, y, state).
+    head: dict {'conv': OutConv's Conv2d} when OutConv consumes this layer's output; where the fused kernel applies
+    (training-mode BatchNorm, <= 4 classes) the dict receives 'logits' and 'saved' (what head_fwd would return)."""
     c_in, c_out = conv.in_channels, conv.out_channels
     _check_bn(bn)
     batch_stats = _bn_uses_batch_stats(bn)
@@ -165,6 +167,13 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None):
         ops.bn_train_finalize(stats, n * h * w, _B, st, float(momentum or 0.0), float(bn.eps))
     else:
         ops.bn_eval_params(bn, st, float(bn.eps))
+    if head is not None and pool_out is None and ops.head_fwd_fusable(c_out, head['conv'].out_channels, dtype) \
+            and head['conv'].kernel_size == (1, 1):
+        hc = head['conv']
+        wh = _f32c(hc.weight)
+        act, logits = ops.bn_relu_apply_head(y, st, wh.reshape(hc.out_channels, c_out), _f32c(hc.bias), out=out)
+        head['logits'], head['saved'] = logits, (act, wh)
+        return act, (x, y, st)
     act = ops.bn_relu_apply(y, st, out=out, pool_out=pool_out)
     return act, (x, y, st)
 
@@ -201,11 +210,12 @@ def _grad_buf(grads, p):
 
 
 # ------------------------------------------------------------------------------------ DoubleConv
-def double_conv_fwd(dc, x, dtype, out=None, pool_out=None):
-    """pool_out: optional [N,H//2,W//2,C] buffer that receives MaxPool2d(2) of the block's output (fused)."""
+def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
+    """pool_out: optional [N,H//2,W//2,C] buffer that receives MaxPool2d(2) of the block's output (fused).
+    head: see conv_bn_relu_fwd (OutConv's logits emitted by the block's last kernel)."""
     seq = dc.double_conv
     a1, s1 = conv_bn_relu_fwd(seq[0], seq[1], x, dtype)
-    a2, s2 = conv_bn_relu_fwd(seq[3], seq[4], a1, dtype, out=out, pool_out=pool_out)
+    a2, s2 = conv_bn_relu_fwd(seq[3], seq[4], a1, dtype, out=out, pool_out=pool_out, head=head)
     return a2, (s1, s2)
 
 

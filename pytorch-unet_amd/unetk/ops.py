@@ -280,6 +280,31 @@ def convT2x2_wgrad(x, dcat, choff, dw, db, pad_t, pad_l):
                                   db.data_ptr(), dc, stream_ptr()), 'unetk_channel_sum')
 
 
+def head_fwd_fusable(c, n_classes, dtype):
+    """OutConv shapes whose logits the BatchNorm+ReLU apply kernel can emit (a pixel's lanes share a wave)."""
+    e = 16 // torch.empty(0, dtype=dtype).element_size()
+    ppp = c // e
+    return n_classes <= 4 and c % e == 0 and 0 < ppp <= 64 and (ppp & (ppp - 1)) == 0
+
+
+def bn_relu_apply_head(y, state, w_head, bias, out=None):
+    """relu(bn(y)) AND OutConv's logits [N,H,W,n_classes] of it (w_head fp32 [n_classes, C], bias fp32)."""
+    n, h, w, c, ldy = nhwc_meta(y, 'bn input')
+    ncls = w_head.shape[0]
+    if w_head.dtype != torch.float32 or bias.dtype != torch.float32 or w_head.numel() != ncls * c \
+            or not w_head.is_contiguous():
+        raise RuntimeError('bn_relu_apply_head: OutConv weight must be contiguous fp32 [n_classes, C]')
+    if out is None:
+        out = new_nhwc(n, h, w, c, y.dtype, y.device)
+    _, _, _, _, ldo = nhwc_meta(out, 'bn output')
+    logits = new_nhwc(n, h, w, ncls, y.dtype, y.device)
+    check(fn['unetk_bn_relu_apply_head'](y.data_ptr(), ldy, state.scale.data_ptr(), state.shift.data_ptr(),
+                                         out.data_ptr(), ldo, w_head.data_ptr(), bias.data_ptr(), ncls,
+                                         logits.data_ptr(), ncls, n * h * w, c, dtype_code(y.dtype), stream_ptr()),
+          'unetk_bn_relu_apply_head')
+    return out, logits
+
+
 # ------------------------------------------------------------------------------------ BN + ReLU
 class BNState:
     """Per-layer scale/shift (+ mean/invstd in train mode): [4, C] fp32."""

@@ -507,3 +507,26 @@ def test_bn_relu_bwd_with_head_gradient_equals_conv1x1_dgrad_then_bn_bwd(dtype, 
     assert float((fused.float() - plain.float()).abs().max()) <= tol * float(plain.float().abs().max())
     assert float((dg1 - dg2).abs().max()) <= tol * float(dg2.abs().max())
     assert float((db1 - db2).abs().max()) <= tol * float(db2.abs().max())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ncls,npix_shape', [(1, (2, 9, 13)), (2, (1, 16, 16)), (2, (2, 7, 11)), (3, (1, 5, 9)), (4, (2, 6, 7))])
+def test_bn_relu_apply_head_equals_apply_then_conv1x1(dtype, ncls, npix_shape):
+    """Last block forward (unet_parts.py:20-21 then :74): the fused kernel's activation must equal bn_relu_apply's bit
+    for bit, its logits conv1x1_fwd's on that activation (same per-lane fma chain and shuffle order: bit for bit)."""
+    from unetk import ops
+    torch.manual_seed(ncls * 7 + npix_shape[2])
+    n, h, w = npix_shape
+    c = 64
+    y = torch.randn((n, h, w, c), device='cuda').to(dtype)
+    st = ops.BNState(c, 'cuda')
+    st.buf.uniform_(-1.0, 1.0)
+    wh = torch.randn((ncls, c), device='cuda') * 0.2
+    bias = torch.randn(ncls, device='cuda')
+    cat = torch.full((n, h, w, c + 64), 5.0, device='cuda').to(dtype)
+    act, logits = ops.bn_relu_apply_head(y, st, wh, bias, out=cat[..., :c])
+    ref_act = ops.bn_relu_apply(y, st)
+    ref_logits = ops.conv1x1_fwd(ref_act, wh.reshape(ncls, c, 1, 1), bias, ncls)
+    assert torch.equal(act, ref_act)
+    assert torch.equal(cat[..., c:].float(), torch.full((n, h, w, 64), 5.0, device='cuda'))
+    assert logits.shape == ref_logits.shape and torch.equal(logits, ref_logits)
