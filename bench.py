@@ -136,7 +136,7 @@ def main():
             torch.cuda.synchronize()
         table = kt.summary()
         n_l, ms, fl = 0, 0.0, 0.0
-        for name in ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad'):
+        for name in ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums'):
             if name in table:
                 n_l += table[name][0]
                 ms += table[name][1]

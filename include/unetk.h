@@ -121,6 +121,16 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
                          int pad_l, int accumulate, int dtype, void* stream);
 int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int pad_t, int pad_l, int h_up, int w_up,
                           int dtype, void* stream);
+/* The same bias gradient without a pass over the gradient tensor: the decoder's first conv3x3 dgrad WRITES that tensor
+ * (the concat gradient), and unetk_conv3x3_dgrad_sums -- dgrad with the fused per-channel sums of the conv epilogue,
+ * `sums` [UNETK_STAT_REPLICAS][c_in][2] doubles zeroed by the caller -- hands over the sums of all its pixels;
+ * unetk_convT2x2_bias_grad_from_sums subtracts the F.pad border (a few rows/columns, `dup` = the up-sampled channel
+ * slice, `scratch` c_up doubles) and writes db [c_up]. */
+int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,
+                             double* sums, int n, int h, int w, int c_in, int c_out, int dtype, void* stream);
+int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_off, const void* dup, int ld, int n,
+                                       int hs, int ws, int c_up, int pad_t, int pad_l, int h_up, int w_up,
+                                       double* scratch, float* db, int dtype, void* stream);
 /* out[c] = sum over images and the window [win_y,win_y+win_h) x [win_x,win_x+win_w) of x[n,y,x,c];
  * scratch: c doubles. */
 int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int win_y, int win_x, int win_h, int win_w,

@@ -976,6 +976,11 @@ int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk,
   return conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, nullptr, n, h, w, c_out, c_in, dtype, stream);
 }
 
+int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,
+                             double* sums, int n, int h, int w, int c_in, int c_out, int dtype, void* stream) {
+  return conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, sums, n, h, w, c_out, c_in, dtype, stream);
+}
+
 int unetk_convT2x2_fwd(const void* x, int ldx, const void* wpk, const float* bias, void* y, int ldy, int y_choff,
                        int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype,
                        void* stream) {

@@ -1085,6 +1085,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
     if (blockIdx.y * 256 * E + i < C) unsafeAtomicAdd(sums + blockIdx.y * 256 * E + i, (double)red[i]);
 }
 
+// db[c] = (sum over ALL pixels, from the replicas a conv epilogue accumulated) - (sum over the pad border)
+__global__ void bias_from_sums_kernel(const double* __restrict__ sums, int c_total, int c_off,
+                                      const double* __restrict__ border, float* __restrict__ db, int c_up) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c_up) return;
+  double s = 0;
+  for (int r = 0; r < UNETK_STAT_REPLICAS; ++r) s += sums[((size_t)r * c_total + c_off + c) * 2];
+  db[c] = (float)(s - border[c]);
+}
+
 __global__ void double_to_float_kernel(const double* in, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)in[i];
@@ -1434,6 +1444,41 @@ int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int w
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
+int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_off, const void* dup, int ld, int n,
+                                       int hs, int ws, int c_up, int pad_t, int pad_l, int h_up, int w_up,
+                                       double* scratch, float* db, int dtype, void* stream) {
+  if (int e = check_act(dup, ld, c_up, dtype)) return e;
+  if (!sums || !scratch || !db || n <= 0 || c_off < 0 || c_off + c_up > c_total || pad_t < 0 || pad_l < 0 ||
+      pad_t + h_up > hs || pad_l + w_up > ws || (long)n * hs * ws >= 0x7fffffffL - 4L * kMaxGrid * 256)
+    return UNETK_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch, 0, (size_t)c_up * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
+  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int ppp = c_up / e_;
+  const int pg = ppp < 256 ? ppp : 256;
+  if (256 % pg) return UNETK_ERR_SHAPE;
+  const int lanes = 256 / pg;
+  // the F.pad border (unet_parts.py:62-63) as up to four strips: top rows, bottom rows, left and right columns
+  const int strips[4][4] = {{0, 0, pad_t, ws},
+                            {pad_t + h_up, 0, hs - pad_t - h_up, ws},
+                            {pad_t, 0, h_up, pad_l},
+                            {pad_t, pad_l + w_up, h_up, ws - pad_l - w_up}};
+  for (int k = 0; k < 4; ++k) {
+    const int wy = strips[k][0], wx = strips[k][1], wh = strips[k][2], ww = strips[k][3];
+    if (wh <= 0 || ww <= 0) continue;
+    long gx = ((long)n * wh * ww + lanes - 1) / lanes;
+    if (gx > kMaxGrid) gx = kMaxGrid;
+    dim3 grid((unsigned)gx, (unsigned)((ppp + 255) / 256));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, grid, dim3(256), 0, s, (const T*)dup, ld, n, hs, ws, c_up,
+                                         wy, wx, wh, ww, scratch));
+    UNETK_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(bias_from_sums_kernel, dim3((c_up + 255) / 256), dim3(256), 0, s, sums, c_total, c_off,
+                     (const double*)scratch, db, c_up);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
 int unetk_predict_mask(const void* logits, int ld, int n, int h, int w, int n_classes, int out_h, int out_w,
                        float threshold, int64_t* mask, int dtype, void* stream) {
   if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;

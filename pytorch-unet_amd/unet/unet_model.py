@@ -83,7 +83,8 @@ class _UNetImpl:
             grads.update(init())          # gradients land in one flat, bucket-ordered buffer (unetk.ddp)
         # per-channel accumulators of the 18 BatchNorm backward passes + OutConv's gradient replicas (<= 4 x 65 values)
         ops.begin_stats_arena(dlogits.device,
-                              sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)) + 160)
+                              sum(m.num_features for m in net.modules() if isinstance(m, nn.BatchNorm2d)) + 160 +
+                              sum(u.conv.double_conv[0].in_channels for u in ups))
 
         def done(params):
             if ready is not None:
@@ -96,11 +97,17 @@ class _UNetImpl:
         dcats = [None] * 4
         for k in (3, 2, 1, 0):
             up = ups[k]
-            dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None)
+            # ConvTranspose2d's bias gradient = channel sums of the concat gradient's second half: accumulated by the
+            # epilogue of the dgrad that writes it
+            sums = None
+            if isinstance(up.up, nn.ConvTranspose2d):
+                sums = ops.new_stats(up.conv.double_conv[0].in_channels, dlogits.device)
+            dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None,
+                                          dx_sums=sums)
             if k == 3 and dhead is not None:      # OutConv's gradients came out of up4's BatchNorm backward
                 done([net.outc.conv.weight, net.outc.conv.bias])
             dcats[k] = dcat
-            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True)
+            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True, dcat_sums=sums)
             done(blocks.up_params(up))
         # encoder, deepest first.  A block's output fed the skip connection and the next block's max-pool: its
         # gradient = first half of dcat + scatter(pool gradient), formed inside the BatchNorm backward kernels

@@ -178,10 +178,11 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     return act, (x, y, st)
 
 
-def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None):
+def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
     """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing).
     dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient).
-    dhead: (dlogits, OutConv weight) when OutConv consumed this layer's output (`dact` is then None)."""
+    dhead: (dlogits, OutConv weight) when OutConv consumed this layer's output (`dact` is then None).
+    dx_sums: zeroed [REPLICAS, c_in, 2] accumulator for the per-channel sums of the input gradient."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
     if not _bn_uses_batch_stats(bn):
@@ -198,7 +199,7 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
     ops.conv3x3_wgrad(x, dy, dw)
     if not need_dx:
         return None
-    return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out)
+    return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums)
 
 
 def _grad_buf(grads, p):
@@ -219,11 +220,11 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
     return a2, (s1, s2)
 
 
-def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None):
+def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
     seq = dc.double_conv
     s1, s2 = saved
     da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead)
-    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out)
+    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums)
 
 
 def double_conv_params(dc):
@@ -261,11 +262,13 @@ def up_into_cat(up_mod, x_low, cat, c_skip, dtype):
     return (x_low, h, w, c_low, pad_t, pad_l)
 
 
-def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True):
+def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None):
+    """dcat_sums: per-channel sums of dcat from the dgrad that wrote it (ConvTranspose2d bias gradient for free)."""
     x_low, h, w, c_low, pad_t, pad_l = saved
     if isinstance(up_mod, torch.nn.ConvTranspose2d):
         c_out = up_mod.out_channels
-        ops.convT2x2_wgrad(x_low, dcat, c_skip, _grad_buf(grads, up_mod.weight), _grad_buf(grads, up_mod.bias), pad_t, pad_l)
+        ops.convT2x2_wgrad(x_low, dcat, c_skip, _grad_buf(grads, up_mod.weight), _grad_buf(grads, up_mod.bias), pad_t, pad_l,
+                           sums=dcat_sums)
         if not need_dx:
             return None
         return ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out, h, w,

@@ -141,7 +141,9 @@ def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None):
     return out
 
 
-def conv3x3_dgrad(dy, wpk_d, c_in, out=None):
+def conv3x3_dgrad(dy, wpk_d, c_in, out=None, sums=None):
+    """sums: optional zeroed fp64 [REPLICAS, c_in, 2] that receives the per-channel sums of the written gradient
+    (the conv epilogue's fused statistics; used for the ConvTranspose2d bias gradient)."""
     require_cuda(dy, wpk_d)
     n, h, w, c_out, lddy = nhwc_meta(dy, 'conv3x3 dgrad input')
     if out is None:
@@ -151,6 +153,13 @@ def conv3x3_dgrad(dy, wpk_d, c_in, out=None):
         raise RuntimeError('conv3x3 dgrad: output/weight do not match the input')
     if wpk_d.numel() != 9 * c_in * c_out:
         raise RuntimeError('conv3x3 dgrad: packed weight has the wrong size')
+    if sums is not None:
+        if sums.dtype != torch.float64 or sums.numel() != nat.STAT_REPLICAS * c_in * 2:
+            raise RuntimeError('conv3x3 dgrad: sums buffer must be float64 [REPLICAS, c_in, 2]')
+        check(fn['unetk_conv3x3_dgrad_sums'](dy.data_ptr(), lddy, 0, wpk_d.data_ptr(), out.data_ptr(), lddx, 0,
+                                             sums.data_ptr(), n, h, w, c_in, c_out, dtype_code(dy.dtype), stream_ptr()),
+              'unetk_conv3x3_dgrad_sums')
+        return out
     check(fn['unetk_conv3x3_dgrad'](dy.data_ptr(), lddy, 0, wpk_d.data_ptr(), out.data_ptr(), lddx, 0,
                                     n, h, w, c_in, c_out, dtype_code(dy.dtype), stream_ptr()), 'unetk_conv3x3_dgrad')
     return out
@@ -261,7 +270,9 @@ def convT2x2_dgrad(dcat, choff, wpk_d, c_in, c_out, h, w, pad_t, pad_l):
     return dx
 
 
-def convT2x2_wgrad(x, dcat, choff, dw, db, pad_t, pad_l):
+def convT2x2_wgrad(x, dcat, choff, dw, db, pad_t, pad_l, sums=None):
+    """sums: per-channel sums of ALL pixels of dcat ([REPLICAS, C_total, 2], from conv3x3_dgrad(sums=...)): the bias
+    gradient then needs no pass over dcat (only its pad border is read)."""
     require_cuda(x, dcat, dw, db)
     n, h, w, c_in, ldx = nhwc_meta(x, 'convT input')
     _, hs, ws_, ctot, ldd = nhwc_meta(dcat, 'concat gradient')
@@ -276,6 +287,13 @@ def convT2x2_wgrad(x, dcat, choff, dw, db, pad_t, pad_l):
           'unetk_convT2x2_wgrad')
     up = dcat[..., choff:choff + c_out]
     scratch = workspace(c_out * 8, x.device, 'chsum')
+    if sums is not None:
+        if sums.dtype != torch.float64 or sums.numel() != nat.STAT_REPLICAS * ctot * 2:
+            raise RuntimeError('convT2x2_wgrad: sums must be float64 [REPLICAS, C_total, 2]')
+        check(fn['unetk_convT2x2_bias_grad_from_sums'](sums.data_ptr(), ctot, choff, up.data_ptr(), ldd, n, hs, ws_, c_out,
+                                                       pad_t, pad_l, 2 * h, 2 * w, scratch.data_ptr(), db.data_ptr(), dc,
+                                                       stream_ptr()), 'unetk_convT2x2_bias_grad_from_sums')
+        return
     check(fn['unetk_channel_sum'](up.data_ptr(), ldd, n, hs, ws_, c_out, pad_t, pad_l, 2 * h, 2 * w, scratch.data_ptr(),
                                   db.data_ptr(), dc, stream_ptr()), 'unetk_channel_sum')
 

@@ -156,3 +156,26 @@ def test_unet_full_size_train_step_runs_and_is_finite():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     bn = net.inc.double_conv[1]
     assert int(bn.num_batches_tracked) == 1 and torch.isfinite(bn.running_var).all()
+
+
+@pytest.mark.parametrize('n,h,w,c', [(1, 320, 479, 128), (2, 40, 59, 1024), (2, 9, 11, 128)])
+def test_convT_bias_gradient_from_dgrad_sums_exact_on_integers(n, h, w, c):
+    """The ConvTranspose2d bias gradient taken from the fused channel sums of the conv3x3 dgrad that writes the concat
+    gradient (minus its F.pad border): integer operands -> must equal the exact sum over the up-sampled window."""
+    from unetk import ops
+    cout = c // 2                                        # decoder conv: c (concat) -> cout; transposed conv: c -> c/2
+    hs, ws = 2 * h + 1, 2 * w + 1                        # odd sizes: one pad row at the bottom, one column on the right
+    dy = _ints((n, hs, ws, cout), 21).cuda()
+    wd = _ints((cout, c, 3, 3), 22, min(1.0, 24.0 / (9 * cout))).cuda()
+    sums = ops.new_stats(c, 'cuda')
+    dcat = ops.conv3x3_dgrad(dy.bfloat16(), ops.pack_weight(1, wd, cout, c, torch.bfloat16), c, sums=sums)
+    assert dcat.float().abs().max() <= 256
+    x = _ints((n, h, w, c), 23).cuda().bfloat16()
+    dw = torch.empty((c, c // 2, 2, 2), device='cuda')
+    db = torch.empty(c // 2, device='cuda')
+    ops.convT2x2_wgrad(x, dcat, c // 2, dw, db, 0, 0, sums=sums)
+    ref = dcat[:, :2 * h, :2 * w, c // 2:].float().sum((0, 1, 2))
+    assert torch.equal(db, ref)
+    db2 = torch.empty_like(db)
+    ops.convT2x2_wgrad(x, dcat, c // 2, dw, db2, 0, 0)
+    assert torch.equal(db2, ref)
