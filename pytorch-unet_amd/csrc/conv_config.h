@@ -9,9 +9,8 @@ struct Conv3Config { int NB, KS; };
 // n_gemm = GEMM-N channel count (c_out for fprop, c_in for dgrad)
 static inline Conv3Config conv3_config(int n_gemm) {
   static const int force_nb = getenv("UNETK_CONV_NB") ? atoi(getenv("UNETK_CONV_NB")) : 0;
-  static const int small_ks = getenv("UNETK_CONV_KS64") ? atoi(getenv("UNETK_CONV_KS64")) : 2;   // perf A/B
   if (n_gemm % 128 == 0 && force_nb != 2) return {4, 1};   // 128-channel tiles: fewer LDS bytes per MFMA
-  return {2, small_ks == 1 ? 1 : 2};
+  return {2, 2};
 }
 
 // ConvTranspose2d k2 s2 forward / dgrad (pointwise GEMMs): 128-channel n-tiles (NB = 4, the double-buffered kernel)

@@ -894,24 +894,20 @@ template <typename T, int NB, int MODE> int launch(const ConvParams& P, hipStrea
 
 template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) {
   if constexpr (MODE == 0) {
-    constexpr int gen = 2;   // conv3x3 always runs the double-buffered LDS-DMA kernel; the register-staged kernel
-                             // above still serves the transposed-conv modes
+    // conv3x3 always runs the double-buffered LDS-DMA kernel (conv3x3_db_kernel); the register-staged first generation
+    // below still serves the transposed-conv modes whose GEMM-N is not a multiple of 128
     const Conv3Config cfg = conv3_config(P.Cout);
-    if (gen == 2 || cfg.NB == 4) {
-      if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-      if (P.aff_scale != nullptr) {     // inference epilogue (bf16 only: BASELINE.json configs[2])
-        if (dtype != UNETK_BF16) return UNETK_ERR_DTYPE;
-        return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2, true>(P, s) : launch_db<bf16, 2, 2, 8, 2, 2, true>(P, s);
-      }
-      static const int ki = getenv("UNETK_CONV_KI") ? atoi(getenv("UNETK_CONV_KI")) : 2;   // 1: A/B against 32-B input rows
-      if (cfg.NB == 4 && ki == 2)
-        return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
-      if (cfg.NB == 4) return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8>(P, s) : launch_db<float, 4, 1, 8>(P, s);
-      // 64-channel-wide outputs (measured: two 4-wave workgroups per CU with 32-byte chunks were 10 % slower)
-      if (cfg.KS == 1)    // perf A/B (UNETK_CONV_KS64=1): 32 x 32-pixel tiles, 4 row blocks per wave (0.75 KiB LDS / MFMA)
-        return dtype == UNETK_BF16 ? launch_db<bf16, 2, 1, 8, 4>(P, s) : launch_db<float, 2, 1, 8, 4>(P, s);
-      return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
+    if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+    if (P.aff_scale != nullptr) {     // inference epilogue (bf16 only: BASELINE.json configs[2])
+      if (dtype != UNETK_BF16) return UNETK_ERR_DTYPE;
+      return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2, true>(P, s) : launch_db<bf16, 2, 2, 8, 2, 2, true>(P, s);
     }
+    // 128-channel tiles: 64-byte input rows (KI = 2) refilled every second weight chunk; 64-channel tiles: 16 x 32
+    // pixels, 32-channel chunks (measured slower and removed: 32-byte rows for the wide tiles -7 %, 32 x 32-pixel
+    // tiles with four row blocks per wave -6 %, two 4-wave workgroups per CU -10 %)
+    if (cfg.NB == 4)
+      return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
+    return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
   }
   if constexpr (MODE != 0) {
     if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)
@@ -920,8 +916,10 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       return UNETK_ERR_DTYPE;
     }
   }
-  if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);
-  if (dtype == UNETK_F32) return launch<float, 2, MODE>(P, s);
+  if constexpr (MODE != 0) {       // the first-generation kernel serves only the transposed-conv modes
+    if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);
+    if (dtype == UNETK_F32) return launch<float, 2, MODE>(P, s);
+  }
   return UNETK_ERR_DTYPE;
 }
 
