@@ -48,7 +48,7 @@ int unetk_pack_weight(int kind, const float* src, void* dst, int c_out, int c_in
 
 /* All weights of a network in one launch.  unetk_pack_plan_build() translates n_items (parameter, packed buffer,
  * kind, channels, dtype) records -- the arguments of n_items unetk_pack_weight() calls -- into an opaque plan in a
- * HOST buffer of unetk_pack_plan_bytes(n_items) bytes and returns the total number of work items (> 0) or an
+ * HOST buffer of unetk_pack_plan_bytes(n_items) bytes and returns the total number of work units (> 0) or an
  * error code; the caller copies the plan to the device once and calls unetk_pack_plan_run() after every optimizer
  * step.  The plan stays valid while the pointers it names do. */
 typedef struct {
@@ -58,7 +58,7 @@ typedef struct {
 } unetk_pack_item;
 int64_t unetk_pack_plan_bytes(int n_items);
 int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* plan_host, int64_t plan_bytes);
-int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_items, void* stream);
+int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_units, void* stream);
 
 /* ---- conv3x3, stride 1, pad 1, no bias: unet_parts.py:16,19 (aten::conv2d) -------------------
  * y[n,y,x,co] = sum_{kh,kw,ci} x[n,y+kh-1,x+kw-1,ci] * w[co,ci,kh,kw]      (zero padding)

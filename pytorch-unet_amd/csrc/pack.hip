@@ -57,73 +57,160 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 struct PlanItem {
   const float* src;
   void* dst;
-  long long piece_begin;     // first work item (a group of all taps' pieces) of this entry in the concatenated index space
+  long long piece_begin;     // first UNIT (64 groups; a group = all taps' pieces of one 16-byte K run) of this entry
   int kind, c_out, c_in, dtype;
   int N, K, taps, KS, outer, NB;
   int pad_[2];
 };
 static_assert(sizeof(PlanItem) % 8 == 0, "plain layout");
 
-// One thread packs ALL taps of one (output channel, E consecutive K-channels) group: its reads are the contiguous
-// taps of each (o, i) pair of the PyTorch layout (a 288-byte run for conv3x3 fprop), its writes one 16-byte piece
-// per tap, adjacent lanes writing adjacent pieces of the same fragment.  (One thread per piece re-read every
-// 32-byte sector of the parameter eight times.)
+// A wave packs one UNIT = 64 groups, a group = all taps of (one GEMM-N channel o, E consecutive GEMM-K channels).
+// What a unit covers is chosen per kind so that BOTH sides move whole cache lines (one thread per group with
+// fragment-order lanes read 64 different lines per load instruction: the launch was bound by the texture addresser
+// at 0.35 ms for 124 MB):
+//   kind 0 (conv3x3 fprop, src [o][i][9])   unit = fragment set (nt, kc, ks, nb).  The 32 channels o of the set each
+//           own a contiguous run of 2E*9 floats: the wave copies the 32 runs with coalesced 16-byte loads into LDS
+//           (row pitch odd: conflict-free) and the lanes pick their 9 x E values from there; stores are whole 1-KiB
+//           fragments.
+//   kind 1 (conv3x3 dgrad, src [i][o][9])   unit = 64 consecutive o x (kc, ks, h): adjacent lanes read adjacent 36-byte
+//           runs; a store instruction writes NB runs of 64/NB adjacent 16-byte slots.
+//   kinds 2, 3 (ConvTranspose2d, 9 % of the parameters)   fragment-order lanes, direct loads.
+constexpr int kPackWaves = 4;
+
 template <typename T>
-__device__ __forceinline__ void pack_group(const PlanItem& it, long gidx) {
+__device__ __forceinline__ void store_piece_of(const PlanItem& it, int nt, int kc, int ks, int nb, int lane, int t,
+                                               const float (&v)[ElemTraits<T>::E]) {
   constexpr int E = ElemTraits<T>::E;
+  const int nchunks = it.K / (2 * it.KS * E);
+  const int tap_out = it.outer > 1 ? t : 0, tap_in = it.outer > 1 ? 0 : t;
+  // fragment index = ((((nt*outer + tap_out)*nchunks + kc)*taps + tap_in)*KS + ks)*NB + nb
+  const long frag = (((((long)nt * it.outer + tap_out) * nchunks + kc) * it.taps + tap_in) * it.KS + ks) * it.NB + nb;
+  T out[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) out[e] = from_f32<T>(v[e]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + (frag * 64 + lane) * E) = *reinterpret_cast<const uint4*>(out);
+}
+
+// kind 0, phase 1: the unit's 32 parameter runs -> LDS rows
+template <typename T>
+__device__ __forceinline__ void stage_kind0(const PlanItem& it, long unit, int lane, float* rows) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int RUN = 2 * E * 9, NQ = RUN / 4, RP = RUN + 1;
+  const int nchunks = it.K / (2 * it.KS * E);
+  long f = unit;
+  const int nb = (int)(f % it.NB); f /= it.NB;
+  const int ks = (int)(f % it.KS); f /= it.KS;
+  const int kc = (int)(f % nchunks); f /= nchunks;
+  const int nt = (int)f;
+  const int i_base = kc * (2 * it.KS * E) + ks * 2 * E;
+  for (int q = lane; q < 32 * NQ; q += 64) {
+    const int r = q / NQ, c = q - r * NQ;
+    const int o = nt * 32 * it.NB + it.NB * r + nb;
+    const float4 v = *reinterpret_cast<const float4*>(it.src + ((long)o * it.c_in + i_base) * 9 + 4 * c);
+    float* d = rows + r * RP + 4 * c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void emit_unit(const PlanItem& it, long unit, int lane, const float* rows) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int RP = 2 * E * 9 + 1;
   const int CH = 2 * it.KS * E;
   const int nchunks = it.K / CH;
-  const int ntap = it.taps * it.outer;             // 9 (conv3x3) or 4 (convT: as inner taps for fwd, outer for dgrad)
-  const int lane = (int)(gidx & 63);
-  long f = gidx >> 6;
+  const int ntap = it.taps * it.outer;
+  if (it.kind == 1) {
+    long f = unit;
+    const int h = (int)(f & 1); f >>= 1;
+    const int ks = (int)(f % it.KS); f /= it.KS;
+    const int kc = (int)(f % nchunks); f /= nchunks;
+    const int o = (int)f * 64 + lane;                      // 64 consecutive GEMM-N channels
+    const int nt = o / (32 * it.NB), oin = o - nt * 32 * it.NB;
+    const int j = oin / it.NB, nb = oin - j * it.NB;
+    const int i0 = kc * CH + ks * 2 * E + h * E;
+    float v[E][9];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float* p = it.src + ((long)(i0 + e) * it.c_in + o) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[e][t] = p[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float w[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) w[e] = v[e][8 - t];      // dgrad: rotated kernel
+      store_piece_of<T>(it, nt, kc, ks, nb, h * 32 + j, t, w);
+    }
+    return;
+  }
+  long f = unit;
   const int nb = (int)(f % it.NB); f /= it.NB;
   const int ks = (int)(f % it.KS); f /= it.KS;
   const int kc = (int)(f % nchunks); f /= nchunks;
   const int nt = (int)f;
   const int j = lane & 31, h = lane >> 5;
+  if (it.kind == 0) {
+    const float* row = rows + j * RP + h * E * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float w[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) w[e] = row[e * 9 + t];
+      store_piece_of<T>(it, nt, kc, ks, nb, lane, t, w);
+    }
+    return;
+  }
   const int o = nt * 32 * it.NB + it.NB * j + nb;
   const int i0 = kc * CH + ks * 2 * E + h * E;
-  float v[E][9];
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int i = i0 + e;
-    long base;
-    if (it.kind == 0) base = ((long)o * it.c_in + i) * 9;
-    else if (it.kind == 1) base = ((long)i * it.c_in + o) * 9;
-    else if (it.kind == 2) { const int ab = o / it.c_out, co = o - ab * it.c_out; base = ((long)i * it.c_out + co) * 4 + ab; }
-    else base = ((long)o * it.c_out + i) * 4;
-    if (it.kind == 2) {
-      v[e][0] = it.src[base];                      // the tap is part of the GEMM-N index: one value per (o, i)
-    } else {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-        if (t < ntap) v[e][t] = it.src[base + t];
-    }
-  }
-  // fragment index = ((((nt*outer + tap_out)*nchunks + kc)*taps + tap_in)*KS + ks)*NB + nb
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
+  for (int t = 0; t < 4; ++t) {
     if (t >= ntap) continue;
-    const int tap_out = it.outer > 1 ? t : 0, tap_in = it.outer > 1 ? 0 : t;
-    const int tsrc = it.kind == 1 ? 8 - t : t;     // dgrad: rotated kernel
-    const long frag = (((((long)nt * it.outer + tap_out) * nchunks + kc) * it.taps + tap_in) * it.KS + ks) * it.NB + nb;
-    T out[E];
+    float w[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = from_f32<T>(it.kind == 2 ? v[e][0] : v[e][tsrc]);
-    *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + (frag * 64 + lane) * E) = *reinterpret_cast<const uint4*>(out);
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      if (it.kind == 2) {                                  // the tap is part of the GEMM-N index
+        const int ab = o / it.c_out, co = o - ab * it.c_out;
+        w[e] = it.src[((long)i * it.c_out + co) * 4 + ab];
+      } else {
+        w[e] = it.src[((long)o * it.c_out + i) * 4 + t];
+      }
+    }
+    store_piece_of<T>(it, nt, kc, ks, nb, lane, t, w);
   }
 }
 
-__global__ __launch_bounds__(256) void pack_plan_kernel(const PlanItem* __restrict__ plan, int n_items, long total) {
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    int lo = 0, hi = n_items - 1;          // last item whose piece_begin <= idx
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (plan[mid].piece_begin <= idx) lo = mid; else hi = mid - 1;
+__global__ __launch_bounds__(64 * kPackWaves) void pack_plan_kernel(const PlanItem* __restrict__ plan, int n_items,
+                                                                   long total_units) {
+  extern __shared__ float pack_lds[];                      // [kPackWaves][32 rows][145]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* rows = pack_lds + wave * (32 * 145);
+  // the same number of trips for every wave of a block (the barriers below are unconditional)
+  for (long ubase = (long)blockIdx.x * kPackWaves; ubase < total_units; ubase += (long)gridDim.x * kPackWaves) {
+    const long unit = ubase + wave;
+    const bool valid = unit < total_units;
+    PlanItem it{};
+    long local = 0;
+    if (valid) {
+      int lo = 0, hi = n_items - 1;        // last item whose first unit <= unit
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (plan[mid].piece_begin <= unit) lo = mid; else hi = mid - 1;
+      }
+      it = plan[lo];
+      local = unit - it.piece_begin;
+      if (it.kind == 0) {
+        if (it.dtype == UNETK_BF16) stage_kind0<bf16>(it, local, lane, rows);
+        else stage_kind0<float>(it, local, lane, rows);
+      }
     }
-    const PlanItem it = plan[lo];
-    if (it.dtype == UNETK_BF16) pack_group<bf16>(it, idx - it.piece_begin);
-    else pack_group<float>(it, idx - it.piece_begin);
+    __syncthreads();
+    if (valid) {
+      if (it.dtype == UNETK_BF16) emit_unit<bf16>(it, local, lane, rows);
+      else emit_unit<float>(it, local, lane, rows);
+    }
+    __syncthreads();
   }
 }
 
@@ -143,6 +230,7 @@ int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* p
     if (bytes < 0) return bytes;
     if (!u.src || !u.dst) return UNETK_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(u.dst) & 15) return UNETK_ERR_ALIGN;
+    if (u.kind == 0 && (reinterpret_cast<uintptr_t>(u.src) & 15)) return UNETK_ERR_ALIGN;   // 16-byte loads of the runs
     PackGeo g;
     pack_geo(u.kind, u.c_out, u.c_in, &g);
     PlanItem p{};
@@ -150,17 +238,19 @@ int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* p
     p.kind = u.kind; p.c_out = u.c_out; p.c_in = u.c_in; p.dtype = u.dtype;
     p.N = g.N; p.K = g.K; p.taps = g.taps; p.KS = g.KS; p.outer = g.outer; p.NB = g.NB;
     plan[i] = p;
-    total += bytes / 16 / (g.taps * g.outer);      // one work item per (all taps of a 16-byte K group)
+    total += bytes / 16 / (g.taps * g.outer) / 64;   // units: one wave each
   }
   return total;
 }
 
-int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_pieces, void* stream) {
-  if (!plan_dev || n_items <= 0 || total_pieces <= 0) return UNETK_ERR_ARG;
-  long g = (total_pieces + 255) / 256;
+int unetk_pack_plan_run(const void* plan_dev, int n_items, int64_t total_units, void* stream) {
+  if (!plan_dev || n_items <= 0 || total_units <= 0) return UNETK_ERR_ARG;
+  constexpr size_t lds = (size_t)kPackWaves * 32 * 145 * sizeof(float);
+  UNETK_ALLOW_LDS(pack_plan_kernel, lds);
+  long g = (total_units + kPackWaves - 1) / kPackWaves;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(pack_plan_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                     static_cast<const PlanItem*>(plan_dev), n_items, (long)total_pieces);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3((unsigned)g), dim3(64 * kPackWaves), lds, (hipStream_t)stream,
+                     static_cast<const PlanItem*>(plan_dev), n_items, (long)total_units);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
