@@ -1,7 +1,7 @@
 """rocprofv3's default output on this image is a rocpd SQLite file; turn it into the two CSV shapes the other
 scripts and profiles/ use.
 
-  python scripts/rocpd_to_csv.py stats    gpurun_out/prof/x_results.db  profiles/r01f_bench_kernel_stats.csv
+  python scripts/rocpd_to_csv.py stats    gpurun_out/prof/x_results.db  profiles/rNN_bench_kernel_stats.csv
   python scripts/rocpd_to_csv.py counters gpurun_out/pmc/x_results.db   gpurun_out/pmc/x_counter_collection.csv
 """
 import csv
