@@ -254,6 +254,134 @@ __global__ void eval_dice_finalize_kernel(const unsigned long long* __restrict__
 }
 
 
+// ---- multi-class variants that move the logits as whole tiles.  With contiguous logits (pitch == n_classes) a
+// block copies the 256 x n_classes values of 256 consecutive pixels with 16-byte loads into LDS (and, backward, the
+// gradients back out with 16-byte stores); each lane then works on its pixel's row in LDS (row stride n_classes
+// elements: odd for the 21-class case, so conflict-free).  The per-pixel kernels above read n_classes scattered 2/4-byte
+// values per lane, three times over: 2.1 ms backward and 0.8 ms forward for [16,512,512,21] fp32, against ~0.2 ms of
+// HBM time.
+constexpr int kLossTile = 256;
+
+template <typename T>
+__device__ __forceinline__ void loss_tile_load(const T* __restrict__ z, long tile, long npix, int ncls, T* lds) {
+  constexpr int PER = 16 / (int)sizeof(T);
+  const long e0 = tile * kLossTile * ncls;                 // first element of the tile
+  const int nelem = (int)(min((long)kLossTile, npix - tile * kLossTile) * ncls);
+  if (nelem == kLossTile * ncls) {
+    const uint4* src = reinterpret_cast<const uint4*>(z + e0);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int i = threadIdx.x; i < nelem / PER; i += 256) dst[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < nelem; i += 256) lds[i] = z[e0 + i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_fwd_tiled_kernel(const T* __restrict__ z,
+                                                                 const long long* __restrict__ mask, long npix,
+                                                                 int ncls, double* sums) {
+  extern __shared__ __attribute__((aligned(16))) char loss_lds[];
+  T* tile_z = reinterpret_cast<T*>(loss_lds);
+  __shared__ double sh[4];
+  double s_ce = 0, s_pt = 0, s_p = 0, s_t = 0;
+  const long ntiles = (npix + kLossTile - 1) / kLossTile;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    loss_tile_load<T>(z, tile, npix, ncls, tile_z);
+    __syncthreads();
+    const long pix = tile * kLossTile + threadIdx.x;
+    if (pix < npix) {
+      const T* zp = tile_z + threadIdx.x * ncls;
+      const long long t = mask[pix];
+      float m = -INFINITY;
+      for (int k = 0; k < ncls; ++k) m = fmaxf(m, to_f32(zp[k]));
+      float se = 0.f, zt = 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float v = to_f32(zp[k]);
+        se += __expf(v - m);
+        if (k == t) zt = v;
+      }
+      if (t >= 0 && t < ncls) {
+        s_ce += __logf(se) - (zt - m);
+        s_pt += __expf(zt - m) / se;
+        s_t += 1.0;
+      }
+      s_p += 1.0;   // softmax rows sum to one
+    }
+  }
+  s_ce = block_sum(s_ce, sh);
+  s_pt = block_sum(s_pt, sh);
+  s_p = block_sum(s_p, sh);
+  s_t = block_sum(s_t, sh);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(sums + 0, s_ce);
+    unsafeAtomicAdd(sums + 1, s_pt);
+    unsafeAtomicAdd(sums + 2, s_p);
+    unsafeAtomicAdd(sums + 3, s_t);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void seg_loss_bwd_tiled_kernel(const T* __restrict__ z,
+                                                                 const long long* __restrict__ mask, long npix,
+                                                                 int ncls, const float* __restrict__ fin,
+                                                                 const float* gout, T* __restrict__ dz) {
+  extern __shared__ __attribute__((aligned(16))) char loss_lds[];
+  constexpr int PER = 16 / (int)sizeof(T);
+  T* tile_z = reinterpret_cast<T*>(loss_lds);
+  T* tile_d = tile_z + ((kLossTile * ncls + PER - 1) / PER) * PER;
+  const float go = gout ? *gout : 1.f;
+  const float alpha = fin[2];
+  const float inv_m = 1.f / (float)npix;
+  const long ntiles = (npix + kLossTile - 1) / kLossTile;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    loss_tile_load<T>(z, tile, npix, ncls, tile_z);
+    __syncthreads();
+    const long pix = tile * kLossTile + threadIdx.x;
+    if (pix < npix) {
+      const T* zp = tile_z + threadIdx.x * ncls;
+      T* dp = tile_d + threadIdx.x * ncls;
+      const long long t = mask[pix];
+      float m = -INFINITY;
+      for (int k = 0; k < ncls; ++k) m = fmaxf(m, to_f32(zp[k]));
+      float se = 0.f, zt = 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float v = to_f32(zp[k]);
+        se += __expf(v - m);
+        if (k == t) zt = v;
+      }
+      const bool valid = t >= 0 && t < ncls;
+      const float inv = 1.f / se;
+      const float pt = valid ? __expf(zt - m) * inv : 0.f;
+      for (int k = 0; k < ncls; ++k) {
+        const float p = __expf(to_f32(zp[k]) - m) * inv;
+        const float oh = (valid && k == t) ? 1.f : 0.f;
+        const float g = (valid ? (p - oh) * inv_m : 0.f) + alpha * p * (oh - pt);
+        dp[k] = from_f32<T>(go * g);
+      }
+    }
+    __syncthreads();
+    const long e0 = tile * kLossTile * ncls;
+    const int nelem = (int)(min((long)kLossTile, npix - tile * kLossTile) * ncls);
+    if (nelem == kLossTile * ncls) {
+      uint4* dst = reinterpret_cast<uint4*>(dz + e0);
+      const uint4* src = reinterpret_cast<const uint4*>(tile_d);
+      for (int i = threadIdx.x; i < nelem / PER; i += 256) dst[i] = src[i];
+    } else {
+      for (int i = threadIdx.x; i < nelem; i += 256) dz[e0 + i] = tile_d[i];
+    }
+  }
+}
+
+// contiguous rows, 16-byte aligned, more than one class, tiles that fit the default 64 KiB of LDS
+bool loss_tiled_ok(const void* z, int ldz, const void* dz, int lddz, int ncls, int es, bool bwd) {
+  if (ncls < 2 || ldz != ncls || (bwd && lddz != ncls)) return false;
+  if ((reinterpret_cast<uintptr_t>(z) & 15) || (bwd && (reinterpret_cast<uintptr_t>(dz) & 15))) return false;
+  const size_t bytes = ((size_t)kLossTile * ncls * es + 15) / 16 * 16;
+  return (bwd ? 2 * bytes : bytes) <= 60 * 1024;
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,7 +394,16 @@ int unetk_seg_loss_fwd(const void* logits, int ldz, const int64_t* mask, int64_t
   if (hipMemsetAsync(sums4, 0, 4 * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
   long g = (npix + 255) / 256;
   if (g > 2048) g = 2048;
-  if (dtype == UNETK_BF16)
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if (n_classes > 2 && loss_tiled_ok(logits, ldz, nullptr, 0, n_classes, es, false)) {
+    const size_t lds = ((size_t)kLossTile * n_classes * es + 15) / 16 * 16;
+    if (dtype == UNETK_BF16)
+      hipLaunchKernelGGL(seg_loss_fwd_tiled_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, s, (const bf16*)logits,
+                         (const long long*)mask, (long)npix, n_classes, sums4);
+    else
+      hipLaunchKernelGGL(seg_loss_fwd_tiled_kernel<float>, dim3((unsigned)g), dim3(256), lds, s, (const float*)logits,
+                         (const long long*)mask, (long)npix, n_classes, sums4);
+  } else if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(seg_loss_fwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, s, (const bf16*)logits, ldz,
                        (const long long*)mask, (long)npix, n_classes, sums4);
   else
@@ -285,6 +422,20 @@ int unetk_seg_loss_bwd(const void* logits, int ldz, const int64_t* mask, int64_t
   if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
   long g = (npix + 255) / 256;
   if (g > 2048) g = 2048;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if (n_classes > 2 && loss_tiled_ok(logits, ldz, dlogits, lddz, n_classes, es, true)) {
+    const size_t lds = 2 * (((size_t)kLossTile * n_classes * es + 15) / 16 * 16);
+    if (dtype == UNETK_BF16)
+      hipLaunchKernelGGL(seg_loss_bwd_tiled_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                         (const bf16*)logits, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                         (bf16*)dlogits);
+    else
+      hipLaunchKernelGGL(seg_loss_bwd_tiled_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                         (const float*)logits, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                         (float*)dlogits);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(seg_loss_bwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
