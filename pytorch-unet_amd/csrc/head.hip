@@ -226,6 +226,137 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_reduce_kernel(const float* 
   }
 }
 
+// ---- many classes (n_classes > CT, e.g. the 21-class configuration), Cin == 64: the per-class-group kernels above
+// pass over the activation ceil(n_classes/CT) times and store each logit with a scalar store from one lane in 16
+// (2.4 ms forward, 1.6 ms wgrad for [16,512,512] pixels x 21 classes in fp32, 12x their HBM time).  These variants make
+// ONE pass: a block stages 64 pixels x 64 channels in LDS channel-major ([c][65]: a lane per pixel reads a column
+// without bank conflicts), lane (pixel, wave = class group) keeps ceil(n_classes/4) accumulators, the weights come as
+// broadcast 16-byte LDS reads, and the 64 x n_classes logits leave through LDS as one contiguous 16-byte-vector copy.
+constexpr int kHeadPix = 64;       // pixels per trip
+constexpr int kHeadCin = 64;
+constexpr int kHeadMaxGroup = 8;   // classes per lane: n_classes <= 32
+
+template <typename T>
+__device__ __forceinline__ void head_stage_x(const T* __restrict__ x, int ldx, long p0, long npix, float* xs) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int PPP = kHeadCin / E;                       // 16-byte pieces per pixel
+  for (int i = threadIdx.x; i < kHeadPix * PPP; i += 256) {
+    const int px = i / PPP, piece = i - px * PPP;
+    float v[E];
+    if (p0 + px < npix) load_piece<T>(x + (p0 + px) * ldx + piece * E, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[(piece * E + e) * (kHeadPix + 1) + px] = v[e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_fwd_tiled_kernel(const T* __restrict__ x, int ldx,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias, T* __restrict__ out,
+                                                                long npix, int ncls) {
+  extern __shared__ __attribute__((aligned(16))) float head_lds[];
+  float* xs = head_lds;                                   // [64 c][65]
+  float* ws = head_lds + ((kHeadCin * (kHeadPix + 1) + 3) / 4) * 4;   // [ncls][64], 16-byte aligned
+  T* ot = reinterpret_cast<T*>(ws + ncls * kHeadCin);     // [64 px][ncls]
+  for (int i = threadIdx.x; i < ncls * kHeadCin; i += 256) ws[i] = w[i];
+  const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long ntrips = (npix + kHeadPix - 1) / kHeadPix;
+  for (long trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
+    const long p0 = trip * kHeadPix;
+    __syncthreads();                                      // previous trip's output copy and x reads are done
+    head_stage_x<T>(x, ldx, p0, npix, xs);
+    __syncthreads();
+    float acc[kHeadMaxGroup];
+#pragma unroll
+    for (int q = 0; q < kHeadMaxGroup; ++q) acc[q] = 0.f;
+    for (int c = 0; c < kHeadCin; c += 4) {
+      const float x0 = xs[(c + 0) * (kHeadPix + 1) + px], x1 = xs[(c + 1) * (kHeadPix + 1) + px];
+      const float x2 = xs[(c + 2) * (kHeadPix + 1) + px], x3 = xs[(c + 3) * (kHeadPix + 1) + px];
+#pragma unroll
+      for (int q = 0; q < kHeadMaxGroup; ++q) {
+        const int k = g + 4 * q;                          // wave-uniform
+        if (k < ncls) {
+          const float4 wv = *reinterpret_cast<const float4*>(ws + k * kHeadCin + c);
+          acc[q] = fmaf(x3, wv.w, fmaf(x2, wv.z, fmaf(x1, wv.y, fmaf(x0, wv.x, acc[q]))));
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kHeadMaxGroup; ++q) {
+      const int k = g + 4 * q;
+      if (k < ncls) ot[px * ncls + k] = from_f32<T>(acc[q] + bias[k]);
+    }
+    __syncthreads();
+    const int nelem = (int)(min((long)kHeadPix, npix - p0) * ncls);
+    constexpr int PER = 16 / (int)sizeof(T);
+    T* dst = out + p0 * ncls;
+    if (nelem == kHeadPix * ncls) {
+      for (int i = threadIdx.x; i < nelem / PER; i += 256)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(ot)[i];
+    } else {
+      for (int i = threadIdx.x; i < nelem; i += 256) dst[i] = ot[i];
+    }
+  }
+}
+
+// slab[block][k][c] (c == Cin: bias column) like conv1x1_wgrad_kernel, one pass over x and dl
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_tiled_kernel(const T* __restrict__ x, int ldx,
+                                                                  const T* __restrict__ dl, float* __restrict__ slab,
+                                                                  long npix, int ncls) {
+  extern __shared__ __attribute__((aligned(16))) float head_lds[];
+  float* xs = head_lds;                                   // [64 c][65]
+  float* ds = head_lds + ((kHeadCin * (kHeadPix + 1) + 3) / 4) * 4;   // [ncls][64 px] as float
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float acc[kHeadMaxGroup], accb[kHeadMaxGroup];
+#pragma unroll
+  for (int q = 0; q < kHeadMaxGroup; ++q) acc[q] = accb[q] = 0.f;
+  const long ntrips = (npix + kHeadPix - 1) / kHeadPix;
+  for (long trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
+    const long p0 = trip * kHeadPix;
+    __syncthreads();
+    head_stage_x<T>(x, ldx, p0, npix, xs);
+    const int nelem = (int)(min((long)kHeadPix, npix - p0) * ncls);
+    // class-major in LDS ([k][64 px]): a lane then takes four pixels of one class with one broadcast 16-byte read
+    for (int i = threadIdx.x; i < kHeadPix * ncls; i += 256) {
+      const int p = i / ncls, k = i - p * ncls;
+      ds[k * kHeadPix + p] = i < nelem ? to_f32(dl[p0 * ncls + i]) : 0.f;
+    }
+    __syncthreads();
+    const float* xrow = xs + c * (kHeadPix + 1);
+    for (int p = 0; p < kHeadPix; p += 4) {
+      const float x0 = xrow[p], x1 = xrow[p + 1], x2 = xrow[p + 2], x3 = xrow[p + 3];
+#pragma unroll
+      for (int q = 0; q < kHeadMaxGroup; ++q) {
+        const int k = g + 4 * q;
+        if (k < ncls) {
+          const float4 d = *reinterpret_cast<const float4*>(ds + k * kHeadPix + p);   // broadcast
+          acc[q] = fmaf(d.w, x3, fmaf(d.z, x2, fmaf(d.y, x1, fmaf(d.x, x0, acc[q]))));
+          accb[q] += (d.x + d.y) + (d.z + d.w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kHeadMaxGroup; ++q) {
+    const int k = g + 4 * q;
+    if (k < ncls) {
+      float* row = slab + ((size_t)blockIdx.x * ncls + k) * (kHeadCin + 1);
+      row[c] = acc[q];
+      if (c == 0) row[kHeadCin] = accb[q];
+    }
+  }
+}
+
+size_t head_tiled_lds(int ncls, int es_out) {
+  const size_t xs = ((kHeadCin * (kHeadPix + 1) + 3) / 4) * 4 * sizeof(float);
+  return xs + (size_t)ncls * kHeadCin * sizeof(float) + (((size_t)kHeadPix * ncls * es_out + 15) / 16) * 16;
+}
+
 constexpr int kWgradBlocks = 2048;
 
 int check_head(const void* x, int ldx, int cin, int ncls, int dtype) {
@@ -248,6 +379,20 @@ int unetk_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias,
   if (int e = check_head(x, ldx, c_in, n_classes, dtype)) return e;
   if (!w || !bias || !out || npix <= 0 || ldo < n_classes) return UNETK_ERR_ARG;
   const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  if (n_classes > CT && n_classes <= 4 * kHeadMaxGroup && c_in == kHeadCin && ldo == n_classes &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const size_t lds = head_tiled_lds(n_classes, dtype == UNETK_BF16 ? 2 : 4);
+    long gx = (npix + kHeadPix - 1) / kHeadPix;
+    if (gx > 1024) gx = 1024;
+    if (dtype == UNETK_BF16)
+      hipLaunchKernelGGL(conv1x1_fwd_tiled_kernel<bf16>, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream,
+                         (const bf16*)x, ldx, w, bias, (bf16*)out, (long)npix, n_classes);
+    else
+      hipLaunchKernelGGL(conv1x1_fwd_tiled_kernel<float>, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream,
+                         (const float*)x, ldx, w, bias, (float*)out, (long)npix, n_classes);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   const int ppp = c_in / e_;
   int G = 1;
   while (G * 2 <= ppp && G < 64) G *= 2;
@@ -295,6 +440,22 @@ int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float*
   if (!dl || !dw || !workspace || npix <= 0 || lddl < n_classes) return UNETK_ERR_ARG;
   if (workspace_bytes < unetk_conv1x1_wgrad_workspace_bytes(c_in, n_classes)) return UNETK_ERR_ARG;
   const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  if (n_classes > CT && n_classes <= 4 * kHeadMaxGroup && c_in == kHeadCin && lddl == n_classes) {
+    long gt = (npix + kHeadPix - 1) / kHeadPix;
+    if (gt > 1024) gt = 1024;
+    const size_t lds = head_tiled_lds(n_classes, 4) - (size_t)n_classes * kHeadCin * sizeof(float);
+    if (dtype == UNETK_BF16)
+      hipLaunchKernelGGL(conv1x1_wgrad_tiled_kernel<bf16>, dim3((unsigned)gt), dim3(256), lds, (hipStream_t)stream,
+                         (const bf16*)x, ldx, (const bf16*)dl, (float*)workspace, (long)npix, n_classes);
+    else
+      hipLaunchKernelGGL(conv1x1_wgrad_tiled_kernel<float>, dim3((unsigned)gt), dim3(256), lds, (hipStream_t)stream,
+                         (const float*)x, ldx, (const float*)dl, (float*)workspace, (long)npix, n_classes);
+    UNETK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(n_classes * (c_in + 1)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (int)gt, dw, db, c_in, n_classes);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   const int lanes = 256 / (c_in / e_);
   long gx = (npix + lanes - 1) / lanes;
   if (gx > kWgradBlocks) gx = kWgradBlocks;

@@ -264,7 +264,7 @@ def test_conv1x1_fwd_bwd(dtype, ncls):
 
 # --------------------------------------------------------------------------------------- loss + dice
 @pytest.mark.parametrize('dtype', BOTH)
-@pytest.mark.parametrize('ncls', [1, 2, 21])
+@pytest.mark.parametrize('ncls', [1, 2, 3, 8, 21])
 @pytest.mark.parametrize('empty', [False, True])
 def test_seg_loss_fwd_bwd(dtype, ncls, empty):
     from oracle import ops_numpy as O
