@@ -243,7 +243,7 @@ def test_copy_channels(dtype):
 
 # --------------------------------------------------------------------------------------- head
 @pytest.mark.parametrize('dtype', BOTH)
-@pytest.mark.parametrize('ncls', [1, 2, 21])
+@pytest.mark.parametrize('ncls', [1, 2, 5, 21, 32, 33])
 def test_conv1x1_fwd_bwd(dtype, ncls):
     from oracle import ops_numpy as O
     from unetk import ops
