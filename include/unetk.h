@@ -72,10 +72,12 @@ int unetk_conv3x3_fprop(const void* x, int ldx, int x_choff, const void* wpk, vo
 /* The eval()-mode chain of unet_parts.py:16-18 / 19-21 in one kernel (evaluate.py:10, predict.py:20 put the
  * net in eval mode): y = relu(scale[c] * conv3x3(x) + shift[c]) with scale/shift from unetk_bn_eval_params
  * (running statistics).  The affine + ReLU run on the fp32 accumulators in the epilogue; no pre-BN tensor is
- * written.  bf16 only (UNETK_ERR_DTYPE otherwise: use unetk_conv3x3_fprop + unetk_bn_relu_apply). */
+ * written.  `pool` != NULL ([n][h/2][w/2][c_out], pitch ldp): also the MaxPool2d(2) of y (unet_parts.py:34, floor mode),
+ * taken from the registers of the same epilogue.  bf16 only (UNETK_ERR_DTYPE otherwise: use unetk_conv3x3_fprop +
+ * unetk_bn_relu_apply). */
 int unetk_conv3x3_fprop_bn_relu(const void* x, int ldx, int x_choff, const void* wpk, const float* scale,
-                                const float* shift, void* y, int ldy, int y_choff, int n, int h, int w, int c_in,
-                                int c_out, int dtype, void* stream);
+                                const float* shift, void* y, int ldy, int y_choff, void* pool, int ldp, int n, int h,
+                                int w, int c_in, int c_out, int dtype, void* stream);
 /* dgrad of the same layer (autograd of unet_parts.py:16,19): dx = conv3x3(dy, rot180(w)^T).
  * `wpk` = unetk_pack_weight(kind 1); c_in/c_out are those of the FORWARD layer. */
 int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,

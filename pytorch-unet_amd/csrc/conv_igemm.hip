@@ -33,6 +33,8 @@ struct ConvParams {
   const float* bias;
   const float* aff_scale;   // conv3x3 AFF instantiations: y = relu(scale[c] * conv + shift[c]) (eval-mode BatchNorm2d + ReLU)
   const float* aff_shift;
+  void* pool;                // AFF only: MaxPool2d(2) of the stored activation [N][H/2][W/2][Cout] with pitch ldp, or NULL
+  int ldp;
   double* stats;
   int N, H, W;       // tile grid domain (CONV3: image; PWT/CTD: the low-res grid)
   int Cin, Cout;     // GEMM K channels per tap, GEMM N channels
@@ -533,6 +535,31 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
     float ssum[NB], ssq[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    if constexpr (AFF && MB == 2) {
+      // the encoder's MaxPool2d(2) (unet_parts.py:34) of the activation about to be stored: a wave owns tile rows
+      // 2w, 2w+1 and a lane holds horizontally adjacent pixels in accumulator elements i, i+1 -- every complete
+      // 2x2 window is four registers of one lane.  max commutes with the (monotone) rounding of the store.
+      if (P.pool != nullptr) {
+        const int yy = y0 + 2 * wid;                       // even; the window needs row yy + 1 too
+        T* pimg = reinterpret_cast<T*>(P.pool) + (size_t)img * (P.H / 2) * (P.W / 2) * P.ldp;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const int xx = xl + (i & 3) + 8 * (i >> 2);        // even
+          if (yy + 1 < P.H && xx + 1 < P.W) {
+            float pv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const float a = fmaxf(fmaf(acc[0][nb][i], asc[nb], ash[nb]), 0.f);
+              const float b = fmaxf(fmaf(acc[0][nb][i + 1], asc[nb], ash[nb]), 0.f);
+              const float c = fmaxf(fmaf(acc[1][nb][i], asc[nb], ash[nb]), 0.f);
+              const float d = fmaxf(fmaf(acc[1][nb][i + 1], asc[nb], ash[nb]), 0.f);
+              pv[nb] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+            }
+            store_channels<T, NB>(pimg + ((size_t)(yy >> 1) * (P.W / 2) + (xx >> 1)) * P.ldp + ch0, pv);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int yy = y0 + MB * wid + mb;
@@ -954,12 +981,13 @@ int check_common(const void* x, int ldx, int xoff, const void* y, int ldy, int y
 
 int conv3x3_common(const void* x, int ldx, int xoff, const void* wpk, void* y, int ldy, int yoff, double* stats,
                    int n, int h, int w, int cin, int cout, int dtype, void* stream, const float* aff_scale = nullptr,
-                   const float* aff_shift = nullptr) {
+                   const float* aff_shift = nullptr, void* pool = nullptr, int ldp = 0) {
   if (n <= 0 || h <= 0 || w <= 0 || !x || !wpk || !y) return UNETK_ERR_ARG;
   if (int e = check_common(x, ldx, xoff, y, ldy, yoff, cin, cout, dtype, 64)) return e;
   if ((long)h * w * (ldx > ldy ? ldx : ldy) >= 0x7fffffffL) return UNETK_ERR_SHAPE;   // int32 in-image offsets
   ConvParams P{};
   P.x = x; P.wpk = wpk; P.y = y; P.stats = stats; P.aff_scale = aff_scale; P.aff_shift = aff_shift;
+  P.pool = pool; P.ldp = ldp;
   P.N = n; P.H = h; P.W = w; P.Cin = cin; P.Cout = cout;
   P.ldx = ldx; P.ldy = ldy; P.xoff = xoff; P.yoff = yoff;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = cout / 64;
@@ -976,11 +1004,16 @@ int unetk_conv3x3_fprop(const void* x, int ldx, int x_choff, const void* wpk, vo
 }
 
 int unetk_conv3x3_fprop_bn_relu(const void* x, int ldx, int x_choff, const void* wpk, const float* scale,
-                                const float* shift, void* y, int ldy, int y_choff, int n, int h, int w, int c_in,
-                                int c_out, int dtype, void* stream) {
+                                const float* shift, void* y, int ldy, int y_choff, void* pool, int ldp, int n, int h,
+                                int w, int c_in, int c_out, int dtype, void* stream) {
   if (!scale || !shift) return UNETK_ERR_ARG;
+  if (pool) {
+    const int es = dtype == UNETK_BF16 ? 2 : 4;
+    if (h < 2 || w < 2 || ldp < c_out) return UNETK_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(pool) & 15) || (ldp * es) % 16) return UNETK_ERR_ALIGN;
+  }
   return conv3x3_common(x, ldx, x_choff, wpk, y, ldy, y_choff, nullptr, n, h, w, c_in, c_out, dtype, stream, scale,
-                        shift);
+                        shift, pool, ldp);
 }
 
 int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,

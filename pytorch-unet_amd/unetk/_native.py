@@ -105,7 +105,7 @@ class KernelTimer:
         if name in ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad_sums'):
             return 2.0 * a[8] * a[9] * a[10] * 9 * a[11] * a[12]
         if name == 'unetk_conv3x3_fprop_bn_relu':
-            return 2.0 * a[9] * a[10] * a[11] * 9 * a[12] * a[13]
+            return 2.0 * a[11] * a[12] * a[13] * 9 * a[14] * a[15]
         if name == 'unetk_conv3x3_dgrad':
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
         if name == 'unetk_conv3x3_wgrad':

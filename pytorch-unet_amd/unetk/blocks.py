@@ -140,7 +140,9 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
         else:
             if x.dtype != dtype:
                 x = x.to(dtype)
-            act = ops.conv3x3_fprop_bn_relu(x, packed_weight(conv, 0, dtype, c_out, c_in), c_out, st, out=out)
+            act = ops.conv3x3_fprop_bn_relu(x, packed_weight(conv, 0, dtype, c_out, c_in), c_out, st, out=out,
+                                            pool_out=pool_out)
+            pool_out = None                               # came out of the same epilogue
         if pool_out is not None:
             ops.maxpool_into(act, pool_out)
         return act, (x, None, st)

@@ -124,8 +124,9 @@ def conv3x3_fprop(x, wpk, c_out, out=None, stats=None):
     return out
 
 
-def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None):
-    """relu(scale * conv3x3(x) + shift) in one kernel (eval-mode BatchNorm folded into the conv epilogue; bf16)."""
+def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None, pool_out=None):
+    """relu(scale * conv3x3(x) + shift) in one kernel (eval-mode BatchNorm folded into the conv epilogue; bf16);
+    pool_out: optional [N,H//2,W//2,C] that receives MaxPool2d(2) of the result from the same epilogue."""
     require_cuda(x, wpk)
     n, h, w, c_in, ldx = nhwc_meta(x, 'conv3x3 input')
     if out is None:
@@ -135,9 +136,15 @@ def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None):
         raise RuntimeError('conv3x3: output/weight do not match the input')
     if wpk.numel() != 9 * c_in * c_out or state.scale.numel() != c_out:
         raise RuntimeError('conv3x3: packed weight / BatchNorm coefficients have the wrong size')
+    ldp = 0
+    if pool_out is not None:
+        pn, ph, pw, pc, ldp = nhwc_meta(pool_out, 'pool output')
+        if (pn, ph, pw, pc) != (n, h // 2, w // 2, c_out) or pool_out.dtype != x.dtype:
+            raise RuntimeError('conv3x3: pool_out must be [N, H//2, W//2, C] of the activation dtype')
     check(fn['unetk_conv3x3_fprop_bn_relu'](x.data_ptr(), ldx, 0, wpk.data_ptr(), state.scale.data_ptr(),
-                                            state.shift.data_ptr(), out.data_ptr(), ldy, 0, n, h, w, c_in, c_out,
-                                            dtype_code(x.dtype), stream_ptr()), 'unetk_conv3x3_fprop_bn_relu')
+                                            state.shift.data_ptr(), out.data_ptr(), ldy, 0, _ptr(pool_out), ldp,
+                                            n, h, w, c_in, c_out, dtype_code(x.dtype), stream_ptr()),
+          'unetk_conv3x3_fprop_bn_relu')
     return out
 
 

@@ -392,7 +392,10 @@ def test_conv3x3_fprop_bn_relu_equals_conv_then_eval_bn(cin, cout):
     st = ops.BNState(cout, 'cuda')
     ops.bn_eval_params(bn, st, bn.eps)
     cat = torch.full((n, h, w, cout + 64), 7.0, dtype=torch.bfloat16, device='cuda')   # output = channel slice
-    got = ops.conv3x3_fprop_bn_relu(x, wpk, cout, st, out=cat[..., :cout])
+    pooled = torch.full((n, h // 2, w // 2, cout), -1.0, dtype=torch.bfloat16, device='cuda')
+    got = ops.conv3x3_fprop_bn_relu(x, wpk, cout, st, out=cat[..., :cout], pool_out=pooled)
+    # the MaxPool2d(2) of the stored activation comes out of the same epilogue (floor mode: odd last row/column dropped)
+    assert torch.equal(pooled, ops.maxpool_fwd(got.contiguous()))
     assert torch.equal(cat[..., cout:].float(), torch.full((n, h, w, 64), 7.0, device='cuda')), 'wrote past its slice'
     with torch.no_grad():
         y = F.conv2d(x.float().permute(0, 3, 1, 2), wt.bfloat16().float(), padding=1)
