@@ -880,44 +880,58 @@ __device__ __forceinline__ void ac_tap(int o, float scale, int n_in, int& i0, in
 }
 
 template <typename T>
-__global__ void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int h, int w,
-                                    int C, int Hs, int Ws, int padT, int padL) {
+__device__ __forceinline__ void load_cached(const T* p, float (&v)[Vec<T>::E]) {
+  // the four taps of neighbouring outputs overlap: ordinary (cacheable) loads, not the streaming ones of Vec<T>::load
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < Vec<T>::E; ++i) v[i] = raw_elem<T>(raw, i);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
+                                                           int N, int h, int w, int C, int Hs, int Ws, int padT,
+                                                           int padL) {
   constexpr int E = Vec<T>::E;
   const int ppp = C / E;
   const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
   const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-  const long total = (long)N * Hs * Ws * ppp;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long r = idx;
-    const int c0 = (int)(r % ppp) * E; r /= ppp;
-    const int X = (int)(r % Ws); r /= Ws;
-    const int Y = (int)(r % Hs);
-    const long n = r / Hs;
-    const int oy = Y - padT, ox = X - padL;
-    float o[E];
-    if (oy >= 0 && oy < 2 * h && ox >= 0 && ox < 2 * w) {
-      int y0, y1, x0, x1;
-      float fy, fx;
-      ac_tap(oy, sy, h, y0, y1, fy);
-      ac_tap(ox, sx, w, x0, x1, fx);
-      float a[E], b[E], c[E], d[E];
-      const T* base = x + n * h * w * (long)ldx + c0;
-      Vec<T>::load(base + ((long)y0 * w + x0) * ldx, a);
-      Vec<T>::load(base + ((long)y0 * w + x1) * ldx, b);
-      Vec<T>::load(base + ((long)y1 * w + x0) * ldx, c);
-      Vec<T>::load(base + ((long)y1 * w + x1) * ldx, d);
+  // one block row of the grid per destination row (n, Y): no 64-bit divisions, the row's taps y0/y1/fy are uniform
+  const int rows = N * Hs;
+  const int per_row = Ws * ppp;
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int n = row / Hs, Y = row - n * Hs;
+    const int oy = Y - padT;
+    const bool row_in = oy >= 0 && oy < 2 * h;
+    int y0 = 0, y1 = 0;
+    float fy = 0.f;
+    if (row_in) ac_tap(oy, sy, h, y0, y1, fy);
+    const T* base = x + (size_t)n * h * w * ldx;
+    T* orow = out + (size_t)row * Ws * ldo;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < per_row; it += gridDim.x * 256) {
+      const int X = it / ppp, c0 = (it - X * ppp) * E;
+      const int ox = X - padL;
+      float o[E];
+      if (row_in && ox >= 0 && ox < 2 * w) {
+        int x0, x1;
+        float fx;
+        ac_tap(ox, sx, w, x0, x1, fx);
+        float a[E], b[E], c[E], d[E];
+        load_cached<T>(base + (size_t)(y0 * w + x0) * ldx + c0, a);
+        load_cached<T>(base + (size_t)(y0 * w + x1) * ldx + c0, b);
+        load_cached<T>(base + (size_t)(y1 * w + x0) * ldx + c0, c);
+        load_cached<T>(base + (size_t)(y1 * w + x1) * ldx + c0, d);
 #pragma unroll
-      for (int i = 0; i < E; ++i)
-        o[i] = (1.f - fy) * ((1.f - fx) * a[i] + fx * b[i]) + fy * ((1.f - fx) * c[i] + fx * d[i]);
-    } else {
+        for (int i = 0; i < E; ++i)
+          o[i] = (1.f - fy) * ((1.f - fx) * a[i] + fx * b[i]) + fy * ((1.f - fx) * c[i] + fx * d[i]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < E; ++i) o[i] = 0.f;
+        for (int i = 0; i < E; ++i) o[i] = 0.f;
+      }
+      Vec<T>::store(orow + (size_t)X * ldo + c0, o);
     }
-    Vec<T>::store(out + ((n * Hs + Y) * Ws + X) * ldo + c0, o);
   }
 }
 
-// gather form of the adjoint: every input pixel sums the destination pixels that sampled it
 template <typename T>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dcat, int ldd, T* __restrict__ dx, int lddx, int N, int h,
                                     int w, int C, int Hs, int Ws, int padT, int padL) {
@@ -1377,8 +1391,12 @@ int unetk_bilinear2x_fwd(const void* x, int ldx, void* out, int ldo, int n, int 
   if (int e = check_act(out, ldo, c, dtype)) return e;
   if (n <= 0 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws)
     return UNETK_ERR_SHAPE;
-  const long items = (long)n * hs * ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
+  const int per_row = ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  if ((long)n * hs > 0x7fffffffL || (long)h * w >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+  const int gx = (per_row + 255) / 256 > 8 ? 8 : (per_row + 255) / 256;
+  const long rows = (long)n * hs;
+  const int gy = (int)(rows > 4096 ? 4096 : rows);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)x, ldx, (T*)out, ldo, n, h, w, c, hs, ws, pad_t, pad_l));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
