@@ -68,6 +68,20 @@ def pmc_traffic():
         return None
 
 
+def pmc_mfma_busy():
+    """Matrix-pipe busy fraction of the conv3x3 fprop/dgrad launches from the committed counter pass of THIS command
+    (profiles/*_mfma_util.json, scripts/pmc_mfma_util.py): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_mfma_util.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get('conv3x3_db_kernel', {}).get('mfma_busy_fraction')
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -147,7 +161,8 @@ def main():
                         'kernel': 'conv3x3_db_kernel<bf16> (conv3x3 fprop + dgrad launches of one step; '
                                   '128-channel NB=4 and 64-channel NB=2 instantiations)',
                         'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': 2500.0,
-                        'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': pmc_traffic()}
+                        'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': pmc_traffic(),
+                        'mfma_busy_counters': pmc_mfma_busy()}
         total_ms = sum(v[1] for v in table.values())
         sys.stderr.write('kernel-time table of one step (HIP events, serialised by the event brackets):\n')
         for name, (n, m, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):
