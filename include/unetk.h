@@ -86,7 +86,8 @@ int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk,
 /* wgrad of the same layer (autograd of unet_parts.py:16,19): dw[co,ci,kh,kw] = sum x[n,y+kh-1,x+kw-1,ci]*dy[n,y,x,co],
  * written (accumulate=0) or added (1) into the fp32 PyTorch-layout gradient `dw` [Co][Ci][3][3].  Split-K partial
  * sums go through `workspace` (size from unetk_wgrad_workspace_bytes, kind 0 = conv3x3, 1 = convT2x2) and are
- * added in a fixed order: bitwise reproducible.  bf16 activations only (UNETK_ERR_DTYPE otherwise). */
+ * added in a fixed order: bitwise reproducible.  bf16 activations (bf16 MFMA, transposed LDS reads) or fp32
+ * (exact-fp32 MFMA). */
 int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int c_out);
 int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                         int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int accumulate, int dtype,
@@ -116,8 +117,8 @@ int unetk_convT2x2_fwd(const void* x, int ldx, const void* wpk, const float* bia
                        void* stream);
 int unetk_convT2x2_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int n, int h,
                          int w, int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream);
-/* dw [c_in][c_out][2][2] fp32; the bias gradient is a plain per-channel sum (unetk_bn_relu_bwd_* is not involved):
- * it is produced by unetk_channel_sum. */
+/* dw [c_in][c_out][2][2] fp32; the bias gradient is a plain per-channel sum over the up-sampled window: by
+ * unetk_channel_sum, or without a pass of its own by unetk_convT2x2_bias_grad_from_sums (below). */
 int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int dy_choff, float* dw, void* workspace,
                          int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t,
                          int pad_l, int accumulate, int dtype, void* stream);
