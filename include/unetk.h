@@ -31,6 +31,7 @@ extern "C" {
 #define UNETK_ERR_ALIGN (-3)   /* pointer or pitch not aligned to 16 bytes where required */
 #define UNETK_ERR_LAUNCH (-4)  /* hipGetLastError() after launch */
 #define UNETK_ERR_ARG (-5)
+#define UNETK_ERR_TOO_LARGE (-6) /* problem exceeds the fixed capacity of a no-allocation entry point */
 
 /* Library / ABI version and the gfx target it was built for ("gfx950"). */
 int unetk_version(void);
@@ -254,6 +255,17 @@ int unetk_dice_bwd(const float* target, const float* coef, const float* grad_out
 int64_t unetk_eval_dice_workspace_bytes(int n, int n_classes);
 int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
                     float eps, void* workspace, int64_t workspace_bytes, float* dice_out, int dtype, void* stream);
+/* The same metric for callers that cannot allocate (code under HIP graph capture, tight serving / validation loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference, which allocates freely through PyTorch.
+ * Same arguments and result as unetk_eval_dice minus the workspace: the per-(image, class) counters live in a
+ * file-scope device array of the library (UNETK_EVAL_NOALLOC_MAX_GROUPS * 24 bytes = 96 KiB per GPU, held until the
+ * process ends); the call itself performs no hipMalloc/hipFree.  n * n_classes > UNETK_EVAL_NOALLOC_MAX_GROUPS
+ * returns UNETK_ERR_TOO_LARGE (use unetk_eval_dice with a workspace).  All calls on one GPU share that array: calls
+ * on the SAME stream are ordered and safe; calls that overlap on one GPU (different streams, or threads launching
+ * concurrently) race on the counters and must be serialised by the caller. */
+#define UNETK_EVAL_NOALLOC_MAX_GROUPS 4096
+int unetk_eval_dice_noalloc(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes,
+                            int first_class, float eps, float* dice_out, int dtype, void* stream);
 
 /* ---- prediction mask --------------------------------------------------------------------
  * Replaces reference predict.py:26-31: F.interpolate(output, (out_h, out_w), mode='bilinear') (align_corners=False)

@@ -382,6 +382,59 @@ bool loss_tiled_ok(const void* z, int ldz, const void* dz, int lddz, int ncls, i
   return (bwd ? 2 * bytes : bytes) <= 60 * 1024;
 }
 
+
+int eval_dice_check(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
+                    const float* dice_out, int dtype) {
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!logits || !mask || !dice_out) return UNETK_ERR_ARG;
+  if (n <= 0 || n > 65535 || hw <= 0 || n_classes < 2 || n_classes > 1024 || ld < n_classes || first_class < 0 ||
+      first_class >= n_classes)
+    return UNETK_ERR_SHAPE;
+  return UNETK_OK;
+}
+
+// memset of the counters + counting pass + finalize, all on `s`; `counts` holds n * n_classes * 3 u64
+int eval_dice_launch(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
+                     float eps, unsigned long long* counts, float* dice_out, int dtype, hipStream_t s) {
+  if (hipMemsetAsync(counts, 0, (size_t)n * n_classes * 3 * sizeof(unsigned long long), s) != hipSuccess)
+    return UNETK_ERR_LAUNCH;
+  long gx = (hw + 255) / 256;
+  const long cap = n >= 2048 ? 1 : 2048 / n;
+  if (gx > cap) gx = cap;
+  const size_t lds = (size_t)4 * n_classes * 3 * sizeof(unsigned);
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(eval_counts_kernel<bf16>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s, (const bf16*)logits,
+                       ld, (const long long*)mask, (long)hw, n_classes, counts);
+  else
+    hipLaunchKernelGGL(eval_counts_kernel<float>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s,
+                       (const float*)logits, ld, (const long long*)mask, (long)hw, n_classes, counts);
+  UNETK_CHECK_LAUNCH();
+  hipLaunchKernelGGL(eval_dice_finalize_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)counts, n,
+                     n_classes, first_class, eps, dice_out);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+// ---- unetk_eval_dice_noalloc: the per-(image, class) counters live in this file-scope device array instead of a
+// caller workspace (96 KiB per GPU the library runs on, held until the process ends).  In HOST code the array's name
+// is only a stand-in for the symbol, not a device address: the address is asked for once per device, with that device
+// current, and only that pointer is handed to hipMemsetAsync and to the kernels.
+__device__ __align__(256) unsigned long long g_eval_scratch[UNETK_EVAL_NOALLOC_MAX_GROUPS * 3];
+constexpr int kMaxDevices = 64;
+unsigned long long* g_eval_scratch_ptr[kMaxDevices];     // per device; 0 = not asked yet
+
+unsigned long long* eval_scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  unsigned long long* p = __atomic_load_n(&g_eval_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (p) return p;
+  void* addr = nullptr;
+  if (hipGetSymbolAddress(&addr, HIP_SYMBOL(g_eval_scratch)) != hipSuccess || !addr) return nullptr;
+  p = static_cast<unsigned long long*>(addr);
+  __atomic_store_n(&g_eval_scratch_ptr[dev], p, __ATOMIC_RELEASE);   // racing first calls store the same address
+  return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -484,31 +537,21 @@ int64_t unetk_eval_dice_workspace_bytes(int n, int n_classes) {
 
 int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
                     float eps, void* workspace, int64_t workspace_bytes, float* dice_out, int dtype, void* stream) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  if (!logits || !mask || !workspace || !dice_out) return UNETK_ERR_ARG;
-  if (n <= 0 || n > 65535 || hw <= 0 || n_classes < 2 || n_classes > 1024 || ld < n_classes || first_class < 0 ||
-      first_class >= n_classes)
-    return UNETK_ERR_SHAPE;
+  if (int e = eval_dice_check(logits, ld, mask, n, hw, n_classes, first_class, dice_out, dtype)) return e;
+  if (!workspace) return UNETK_ERR_ARG;
   if (workspace_bytes < unetk_eval_dice_workspace_bytes(n, n_classes)) return UNETK_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, (size_t)n * n_classes * 3 * sizeof(unsigned long long), s) != hipSuccess)
-    return UNETK_ERR_LAUNCH;
-  long gx = (hw + 255) / 256;
-  const long cap = n >= 2048 ? 1 : 2048 / n;
-  if (gx > cap) gx = cap;
-  const size_t lds = (size_t)4 * n_classes * 3 * sizeof(unsigned);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(eval_counts_kernel<bf16>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s, (const bf16*)logits,
-                       ld, (const long long*)mask, (long)hw, n_classes, (unsigned long long*)workspace);
-  else
-    hipLaunchKernelGGL(eval_counts_kernel<float>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s,
-                       (const float*)logits, ld, (const long long*)mask, (long)hw, n_classes,
-                       (unsigned long long*)workspace);
-  UNETK_CHECK_LAUNCH();
-  hipLaunchKernelGGL(eval_dice_finalize_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)workspace, n,
-                     n_classes, first_class, eps, dice_out);
-  UNETK_CHECK_LAUNCH();
-  return UNETK_OK;
+  return eval_dice_launch(logits, ld, mask, n, hw, n_classes, first_class, eps, (unsigned long long*)workspace, dice_out,
+                          dtype, (hipStream_t)stream);
+}
+
+int unetk_eval_dice_noalloc(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes,
+                            int first_class, float eps, float* dice_out, int dtype, void* stream) {
+  if (int e = eval_dice_check(logits, ld, mask, n, hw, n_classes, first_class, dice_out, dtype)) return e;
+  if ((long)n * n_classes > UNETK_EVAL_NOALLOC_MAX_GROUPS) return UNETK_ERR_TOO_LARGE;
+  unsigned long long* counts = eval_scratch_for_current_device();
+  if (!counts) return UNETK_ERR_LAUNCH;
+  return eval_dice_launch(logits, ld, mask, n, hw, n_classes, first_class, eps, counts, dice_out, dtype,
+                          (hipStream_t)stream);
 }
 
 }  // extern "C"

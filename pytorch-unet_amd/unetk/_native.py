@@ -16,7 +16,8 @@ BF16, F32 = 0, 1
 STAT_REPLICAS = 32
 
 _ERR = {-1: 'unsupported shape/pitch/channel count', -2: 'unsupported dtype', -3: 'misaligned pointer or pitch',
-        -4: 'kernel launch failed', -5: 'bad argument'}
+        -4: 'kernel launch failed', -5: 'bad argument',
+        -6: 'problem exceeds the fixed capacity of this no-allocation entry point'}
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f'{LIB_PATH} not found: build it with `make -C pytorch-unet_amd/csrc` '
