@@ -1,20 +1,36 @@
 #!/usr/bin/env python
 """Headline benchmark: U-Net training images/sec at 959x640, bf16, batch 16 per GPU (BASELINE.json configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, gradients all-reduced on RCCL)
+  python bench.py --gpus N --steps K --warmup W [--config NAME]
+
+N > 1: one rank per GPU, gradients bucket-all-reduced on RCCL.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK/WORLD_SIZE are then in the
+environment) or, when RANK is NOT set, this process starts them itself -- N fresh children through
+torch.distributed.run, before anything here has touched a GPU -- and relays rank 0's JSON line.
 
 A step = the reference's inner training loop body (train.py:97-117) on one batch of synthetic Carvana-shaped
 tensors already resident in HBM: bf16-autocast forward, CE+dice loss, backward, clip_grad_norm_, RMSprop step.
 Rank 0 prints ONE JSON line with the whole-job images/sec plus
   roofline     -- the dominant kernel (NHWC implicit-GEMM conv3x3 on MFMA, fprop+dgrad launches of one step):
-                  algorithmic FLOPs / HIP-event time on the launch stream, against the 2.5 PFLOP/s dense bf16 peak
+                  algorithmic FLOPs / HIP-event time on the launch stream, against the dense MFMA peak of the dtype
   cpu_baseline -- the reference's PyTorch CPU path (oracle/unet_torch.py, a stock-torch.nn restatement) timed on
-                  the box's host cores on a bounded sample (batch 1), kind "port".
+                  the box's host cores on a bounded sample (batch 1), kind "port" (N = 1, default config only).
+
+--config selects the other BASELINE.json configurations (same JSON, own roofline leg); the default is the headline:
+  train959            configs[1]  UNet(3,2,False) bf16 train step, batch 16 @959x640
+  infer959_bilinear   configs[2]  UNet(3,2,True).eval() bf16 inference, batch 64 @959x640
+  train1918           configs[3]  UNet(3,2,False) bf16 train step, batch 8 per GPU @1918x1280
+  train512_c21        configs[4]  UNet(3,21,False) fp32 train step, CE+dice, batch 16 per GPU @512x512
+
+--backend gloo --dry: CPU rehearsal of the multi-rank plumbing (launcher, rank environment, flat gradient buffer,
+bucketed all-reduce, max-over-ranks timing) with NO kernels -- the product has no CPU path; the line says "dry": true
+and its value is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,15 +39,78 @@ for _p in (ROOT, os.path.join(ROOT, 'pytorch-unet_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 H, W = 640, 959
-TRAIN_GFLOP_PER_IMG = 2693.7        # fwd + dgrad + wgrad, no dgrad for the first conv
+
+# name -> (n_classes, bilinear, train, amp, batch per GPU, H, W, GFLOP per image (BASELINE.md / SURVEY 8d), label)
+CONFIGS = {
+    'train959': dict(n_classes=2, bilinear=False, train=True, amp=True, batch=16, h=640, w=959, gflop=2693.7,
+                     metric='train images/sec @959x640 bf16',
+                     workload='UNet(3,2,bilinear=False) Carvana scale=0.5 (959x640) bf16 training step, '
+                              'batch {B} per GPU (BASELINE.json configs[1])'),
+    'infer959_bilinear': dict(n_classes=2, bilinear=True, train=False, amp=True, batch=64, h=640, w=959, gflop=746.49,
+                              metric='inference images/sec @959x640 bf16 bilinear',
+                              workload='UNet(3,2,bilinear=True).eval() bf16 inference, batch {B} per GPU '
+                                       '(BASELINE.json configs[2])'),
+    'train1918': dict(n_classes=2, bilinear=False, train=True, amp=True, batch=8, h=1280, w=1918, gflop=10801.3,
+                      metric='train images/sec @1918x1280 bf16',
+                      workload='UNet(3,2,bilinear=False) Carvana scale=1.0 (1918x1280) bf16 training step, '
+                               'batch {B} per GPU (BASELINE.json configs[3])'),
+    'train512_c21': dict(n_classes=21, bilinear=False, train=True, amp=False, batch=16, h=512, w=512, gflop=1157.1,
+                         metric='train images/sec @512x512 fp32 21 classes',
+                         workload='UNet(3,21,bilinear=False) fp32 training step, CE+dice multiclass, batch {B} per GPU '
+                                  '(BASELINE.json configs[4]; batch size not given there)'),
+}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X_MICROARCH.md: dense bf16 MFMA; fp32-input MFMA
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='train959')
+    ap.add_argument('--batch-size', '-b', type=int, default=None, help='images per GPU (weak scaling); default per config')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=None, help='sanity runs at other sizes; the metric is quoted at the config size')
+    ap.add_argument('--width', type=int, default=None)
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
+    ap.add_argument('--dry', action='store_true', help='CPU rehearsal of the rank plumbing; no kernels, no measurement')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a rank environment: start N FRESH ranks (this process has not touched a GPU and never will)
+    and relay rank 0's JSON line.  Returns the children's exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this image
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    json_line = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith('{') and '"metric"' in s:
+            json_line = s
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if json_line is not None:
+        print(json_line, flush=True)
+    elif rc == 0:
+        sys.stderr.write('bench.py: the ranks exited cleanly but printed no result line\n')
+        rc = 1
+    return rc
 
 
 def cpu_baseline(seconds_budget=25.0):
     """Reference CPU path (stock torch.nn restatement), fp32, channels_last, batch 1, full train step."""
+    import torch
     from oracle.unet_torch import TorchUNet, train_step
     cores = os.cpu_count() or 1
     threads = min(cores, int(os.environ.get('OMP_NUM_THREADS', cores)))
@@ -53,72 +132,136 @@ def cpu_baseline(seconds_budget=25.0):
                       f'torch {torch.__version__} CPU, {threads} threads'}
 
 
-def pmc_traffic():
-    """HBM bytes per conv3x3 fprop/dgrad launch from the committed rocprofv3 --pmc passes of THIS command
-    (profiles/*_conv_traffic.json, made by scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
-    correction of MI355X_MICROARCH.md 'HBM'); counters cannot be read from inside the timed process."""
+def committed_profile(pattern, getter):
+    """A number from the newest committed rocprofv3 --pmc summary under profiles/ (counters cannot be read from
+    inside the timed process).  Returns {'value', 'source'} so the line says where and when it was taken."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_conv_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
     if not files:
         return None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get('hbm_bytes_per_launch')
-    except (OSError, ValueError):
+            doc = json.load(f)
+        v = getter(doc)
+    except (OSError, ValueError, AttributeError):
         return None
-
-
-def pmc_mfma_busy():
-    """Matrix-pipe busy fraction of the conv3x3 fprop/dgrad launches from the committed counter pass of THIS command
-    (profiles/*_mfma_util.json, scripts/pmc_mfma_util.py): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 * 4)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_mfma_util.json')))
-    if not files:
+    if v is None:
         return None
-    try:
-        with open(files[-1]) as f:
-            return json.load(f).get('conv3x3_db_kernel', {}).get('mfma_busy_fraction')
-    except (OSError, ValueError):
-        return None
+    return {'value': v, 'source': os.path.relpath(files[-1], ROOT), 'profiled_at': doc.get('commit') or doc.get('bench_sha')}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch-size', '-b', type=int, default=16, help='images per GPU (weak scaling)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--height', type=int, default=H, help='sanity runs of other BASELINE configs; the metric is quoted at 640')
-    ap.add_argument('--width', type=int, default=W)
-    args = ap.parse_args()
+def dry_run(args, rank, world):
+    """CPU/gloo rehearsal: the flat completion-ordered gradient buffer and its bucketed all-reduce, no kernels."""
+    import torch
+    import torch.distributed as dist
+    from unet import UNet
+    from unetk.ddp import FlatGrads
+    torch.manual_seed(0)
+    net = UNet(3, 2, False)
+    sync = FlatGrads(net, bucket_bytes=25 << 20)
+
+    def step():
+        grads = sync.initial_grads()
+        for blk in FlatGrads._completion_blocks(net):
+            for p in blk:
+                grads[p].fill_(float(rank + 1))
+            sync.ready(blk, grads)
+        sync.finish()
+        return grads
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grads = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    want = sum(range(1, world + 1)) / world
+    ok = all(bool(torch.all(g == want)) for g in grads.values())
+    if not ok:
+        raise RuntimeError(f'rank {rank}: averaged gradients are wrong')
+    return elapsed
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    cfg = CONFIGS[args.config]
+    B = args.batch_size or cfg['batch']
+    hh, ww = args.height or cfg['h'], args.width or cfg['w']
+    dtype_name = 'bf16' if cfg['amp'] else 'f32'
+
+    if args.dry:
+        if args.backend != 'gloo':
+            sys.exit('bench.py: --dry is the CPU rehearsal, use --backend gloo')
+        if world > 1:
+            dist.init_process_group('gloo')
+        elapsed = dry_run(args, rank, world)
+        if rank == 0:
+            print(json.dumps({'metric': cfg['metric'], 'value': None, 'unit': 'images/sec', 'n_gpus': world,
+                              'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name,
+                              'data': 'none', 'dry': True, 'backend': 'gloo',
+                              'config': {'workload': 'DRY RUN: gradient all-reduce plumbing only, no kernels',
+                                         'global_batch': world * B, 'parallelism': f'dp{world}'}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev if args.backend == 'nccl' else None)
 
     from unet import UNet
     from unetk import _native
     from unetk.trainer import Trainer
 
     torch.manual_seed(0)
-    net = UNet(3, 2, False).to(dev).to(memory_format=torch.channels_last).train()
+    net = UNet(3, cfg['n_classes'], cfg['bilinear']).to(dev).to(memory_format=torch.channels_last)
+    net = net.train() if cfg['train'] else net.eval()
     if world > 1:                                    # identical replicas: broadcast rank 0's random init
         for t in list(net.parameters()) + list(net.buffers()):
             dist.broadcast(t.data, 0)
-    trainer = Trainer(net, amp=True)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    B = args.batch_size
-    hh, ww = args.height, args.width
     images = torch.rand((B, 3, hh, ww), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
-    masks = (torch.rand((B, hh, ww), device=dev, generator=g) < 0.2).long()
+    if cfg['n_classes'] == 2:
+        masks = (torch.rand((B, hh, ww), device=dev, generator=g) < 0.2).long()
+    else:
+        masks = torch.randint(0, cfg['n_classes'], (B, hh, ww), device=dev, generator=g)
+
+    if cfg['train']:
+        trainer = Trainer(net, amp=cfg['amp'])
+
+        def step():
+            return trainer.step(images, masks)
+    else:
+        def step():
+            with torch.inference_mode(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=cfg['amp']):
+                return net(images)
 
     for _ in range(args.warmup):
-        trainer.step(images, masks)
+        step()
 
     def barrier():
         if world > 1:
@@ -128,41 +271,55 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(images, masks)
+        res = step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_val = float(res) if cfg['train'] else None
 
     roofline = None
-    table = {}
     # kernel timing pass: one more step (on EVERY rank: it contains the gradient collectives) with, on rank 0,
     # every C-ABI launch bracketed by HIP events on its stream
     if rank != 0:
-        trainer.step(images, masks)
+        step()
         torch.cuda.synchronize()
     else:
         with _native.KernelTimer() as kt:
-            trainer.step(images, masks)
+            step()
             torch.cuda.synchronize()
         table = kt.summary()
         n_l, ms, fl = 0, 0.0, 0.0
-        for name in ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums'):
+        names = ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums', 'unetk_conv3x3_dgrad_bnsums',
+                 'unetk_conv3x3_fprop_bn_relu')
+        for name in names:
             if name in table:
                 n_l += table[name][0]
                 ms += table[name][1]
                 fl += table[name][2]
         if ms > 0:
             achieved = fl / (ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[dtype_name]
             roofline = {'bound': 'mfma',
-                        'kernel': 'conv3x3_db_kernel<bf16> (conv3x3 fprop + dgrad launches of one step; '
-                                  '128-channel NB=4 and 64-channel NB=2 instantiations)',
-                        'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': 2500.0,
-                        'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': pmc_traffic(),
-                        'mfma_busy_counters': pmc_mfma_busy()}
+                        'kernel': f'conv3x3_db_kernel<{"bf16" if cfg["amp"] else "float"}> (the conv3x3 fprop'
+                                  f'{" + dgrad" if cfg["train"] else ""} launches of one step; 128-channel NB=4 and '
+                                  '64-channel instantiations)',
+                        'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': peak,
+                        'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None}
+            if args.config == 'train959' and (hh, ww, B) == (H, W, 16):
+                # counters of THIS command from committed --pmc passes; only quoted for the configuration they were
+                # taken on, with their source
+                tr = committed_profile('*_conv_traffic.json', lambda d: d.get('hbm_bytes_per_launch'))
+                mb = committed_profile('*_mfma_util.json',
+                                       lambda d: d.get('conv3x3_db_kernel', {}).get('mfma_busy_fraction'))
+                if tr:
+                    roofline['traffic'] = tr['value']
+                    roofline['traffic_source'] = tr['source']
+                if mb:
+                    roofline['mfma_busy_counters'] = mb['value']
+                    roofline['mfma_busy_source'] = mb['source']
         total_ms = sum(v[1] for v in table.values())
         sys.stderr.write('kernel-time table of one step (HIP events, serialised by the event brackets):\n')
         for name, (n, m, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):
@@ -170,21 +327,23 @@ def main():
             sys.stderr.write(f'  {name:34s} x{n:3d} {m:9.3f} ms {100 * m / max(total_ms, 1e-9):5.1f}%{tf}\n')
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'train959':
         cpu = cpu_baseline()
 
     if rank == 0:
         ips = world * B * args.steps / elapsed
+        sized = (hh, ww) == (cfg['h'], cfg['w'])
         out = {
-            'metric': f'train images/sec @{ww}x{hh} bf16', 'value': ips, 'unit': 'images/sec', 'n_gpus': world,
+            'metric': cfg['metric'] if sized else f'images/sec @{ww}x{hh} {dtype_name}', 'value': ips,
+            'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'UNet(3,2,bilinear=False) Carvana scale=0.5 (959x640) bf16 training step, '
-                                   f'batch {B} per GPU (BASELINE.json configs[1])' if (hh, ww) == (H, W) else
-                                   f'UNet(3,2,bilinear=False) {ww}x{hh} bf16 training step, batch {B} per GPU (sanity run)',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'optimizer': 'RMSprop+clip_grad_norm',
-                       'loss': 'CE+dice'},
-            'model_tflops': ips * TRAIN_GFLOP_PER_IMG * (hh * ww) / (H * W) / 1e3, 'final_loss': loss_val,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name, 'data': 'synthetic',
+            'config': {'workload': cfg['workload'].format(B=B) if sized else
+                       f'{args.config} at {ww}x{hh}, batch {B} per GPU (sanity run)',
+                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'optimizer': 'RMSprop+clip_grad_norm' if cfg['train'] else None,
+                       'loss': 'CE+dice' if cfg['train'] else None},
+            'model_tflops': ips * cfg['gflop'] * (hh * ww) / (cfg['h'] * cfg['w']) / 1e3, 'final_loss': loss_val,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(out), flush=True)

@@ -10,40 +10,46 @@ is kept literally (evaluate.py:26-29), including its size assertion inside dice_
 un-squeezed [N,1,H,W] prediction against the [N,H,W] mask).  The tqdm progress bar is not reproduced.
 """
 import torch
-import torch.nn.functional as F
 
 from unetk import ops
 from utils.dice_score import dice_coeff
 
 
+def _label_range_ok(labels, upper):
+    lo, hi = torch.aminmax(labels)
+    return bool(lo >= 0) and bool(hi <= upper)
+
+
+def _score_binary(logits, labels):
+    """Single-logit nets (evaluate.py:26-30): threshold the sigmoid at 0.5 and hand the [N,1,H,W] prediction and the
+    [N,H,W] labels to dice_coeff exactly as the reference does -- shapes included, so dice_coeff's own size check
+    fires just as it does there."""
+    assert _label_range_ok(labels, 1), f'binary segmentation labels must be 0 or 1, got up to {int(labels.max())}'
+    hard = torch.sigmoid(logits).gt(0.5).float()
+    return dice_coeff(hard, labels, reduce_batch_first=False)
+
+
+def _score_multiclass(logits, labels, n_classes):
+    """evaluate.py:31-37 without its one-hot temporaries: unetk_eval_dice counts, per image and foreground class,
+    |pred == k|, |label == k| and their overlap in one pass over logits and labels, then averages the Dice ratios."""
+    assert _label_range_ok(labels, n_classes - 1), \
+        f'labels must lie in 0..{n_classes - 1} for a {n_classes}-class net, got up to {int(labels.max())}'
+    return ops.eval_dice(logits, labels, first_class=1)
+
+
 @torch.inference_mode()
 def evaluate(net, dataloader, device, amp):
     net.eval()
-    num_val_batches = len(dataloader)
-    dice_score = 0
-
-    # iterate over the validation set
+    total, n_batches = 0, len(dataloader)
     with torch.autocast(device.type, dtype=torch.bfloat16, enabled=amp):
-        for batch in dataloader:
-            image, mask_true = batch['image'], batch['mask']
-
-            # move images and labels to correct device and type
-            image = image.to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
-            mask_true = mask_true.to(device=device, dtype=torch.long)
-
-            # predict the mask
-            mask_pred = net(image)
-
+        for sample in dataloader:
+            frames = sample['image'].to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
+            labels = sample['mask'].to(device=device, dtype=torch.long)
+            logits = net(frames)
             if net.n_classes == 1:
-                assert mask_true.min() >= 0 and mask_true.max() <= 1, 'True mask indices should be in [0, 1]'
-                mask_pred = (F.sigmoid(mask_pred) > 0.5).float()
-                # compute the Dice score
-                dice_score += dice_coeff(mask_pred, mask_true, reduce_batch_first=False)
+                total = total + _score_binary(logits, labels)
             else:
-                assert mask_true.min() >= 0 and mask_true.max() < net.n_classes, \
-                    'True mask indices should be in [0, n_classes['
-                # argmax -> one-hot -> Dice ignoring background, fused
-                dice_score += ops.eval_dice(mask_pred, mask_true, first_class=1)
-
+                total = total + _score_multiclass(logits, labels, net.n_classes)
+    # the reference unconditionally returns the net to train mode (evaluate.py:39); so does this
     net.train()
-    return dice_score / max(num_val_batches, 1)
+    return total / max(n_batches, 1)

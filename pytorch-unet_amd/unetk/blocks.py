@@ -15,6 +15,11 @@ import torch
 from . import ops
 
 
+# inference: fold eval-mode BatchNorm + ReLU (+ MaxPool2d) into the conv epilogue.  Tests flip it to compare the fused
+# kernels with the unfused chain (conv -> bn_relu_apply -> maxpool) on the same net.
+FUSE_EVAL_EPILOGUE = True
+
+
 def activation_dtype(x):
     """bf16 under torch.autocast (the reference's --amp path, train.py:100), otherwise the input's dtype."""
     if torch.is_autocast_enabled():
@@ -129,7 +134,7 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     batch_stats = _bn_uses_batch_stats(bn)
     n, h, w, _, _ = ops.nhwc_meta(x, 'conv input')
     stats = ops.new_stats(c_out, x.device) if batch_stats else None
-    if not batch_stats and (c_in <= 4 or dtype == torch.bfloat16):
+    if not batch_stats and FUSE_EVAL_EPILOGUE and (c_in <= 4 or dtype == torch.bfloat16):
         # inference (evaluate.py:10, predict.py:20 call net.eval()): BatchNorm with running statistics is a per-channel
         # affine map -> folded with the ReLU into the conv epilogue, no pre-BN tensor, no second pass
         st = ops.BNState(c_out, x.device)

@@ -33,6 +33,7 @@ class FlatGrads:
         # RCCL averages in the collective; gloo (CPU tests) has no AVG, so sum and divide after the wait
         self.native_avg = self.active and dist.get_backend(process_group) == 'nccl'
         self.flat = None
+        self.views = {}
         self._pending = [0, 0]
         self._works = []
         net._grad_ready_hook = self.ready
@@ -55,7 +56,20 @@ class FlatGrads:
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)   # zero: alignment gaps enter the norm
         self._pending = [0, 0]
         self._works = []
-        return {p: self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape) for p in self.params}
+        self.views = {p: self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape)
+                      for p in self.params}
+        return dict(self.views)
+
+    def bind_param_grads(self):
+        """Make every `p.grad` the parameter's view of the flat buffer.  Autograd only *sometimes* keeps the tensor a
+        Function returns as `.grad` (AccumulateGrad clones it when its strides differ from the parameter's, e.g. after
+        `net.to(memory_format=channels_last)`), so anything done to the flat buffer after backward -- the all-reduce
+        average, the clip -- reaches a stock optimizer only through this call."""
+        if self.flat is None:
+            return
+        for p in self.params:
+            if p.requires_grad:
+                p.grad = self.views[p]
 
     def ready(self, params, grads):
         if not params:

@@ -43,8 +43,11 @@ class Trainer:
         loss.backward()
         self.sync.finish()
         flat = self.sync.flat
-        if not self.fused and self.clip is not None and flat is not None:
-            total_norm = torch.linalg.vector_norm(flat)
-            flat.mul_(torch.clamp(self.clip / (total_norm + 1e-6), max=1.0))
+        if not self.fused and flat is not None:
+            if self.clip is not None:
+                total_norm = torch.linalg.vector_norm(flat)
+                flat.mul_(torch.clamp(self.clip / (total_norm + 1e-6), max=1.0))
+            # the flat buffer (averaged over ranks, clipped) is authoritative: hand its views to torch's optimizer
+            self.sync.bind_param_grads()
         self.optimizer.step()
         return loss.detach()

@@ -22,7 +22,9 @@ def _worker(rank, world, port, q):
         from unet import UNet
         from unetk.ddp import FlatGrads
         torch.manual_seed(0)
-        net = UNet(3, 2, False)                               # parameter holders only; no kernel runs on CPU
+        # parameter holders only; no kernel runs on CPU.  channels_last like train.py:197 / bench.py: autograd then
+        # clones 4-D weight gradients instead of keeping the flat views, so the trainer must bind them itself
+        net = UNet(3, 2, False).to(memory_format=torch.channels_last)
         sync = FlatGrads(net, bucket_bytes=4 << 20)
         assert sync.world == 2 and not sync.native_avg
         grads = sync.initial_grads()
@@ -41,6 +43,12 @@ def _worker(rank, world, port, q):
             ok &= bool(torch.all(g.view(-1)[1:] == 1.5))
             ok &= abs(float(g.view(-1)[0]) - 1.5 * float(p.numel() % 97)) < 1e-6
         ok &= sync.total >= sum(p.numel() for p in net.parameters())
+        # what a stock optimizer steps from: p.grad must BE the averaged flat view (Trainer's non-fused path)
+        sync.bind_param_grads()
+        lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + 4 * sync.flat.numel()
+        for p in net.parameters():
+            ok &= lo <= p.grad.data_ptr() < hi and p.grad.shape == p.shape
+            ok &= bool(torch.all(p.grad.reshape(-1)[1:] == 1.5))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -35,6 +35,8 @@ CONV_SHAPES = [
     (1, 640, 959, 128, 64),      # L0 decoder conv on the concat input
     (1, 320, 479, 128, 128),     # 128-channel tiles (NB=4)
     (2, 40, 59, 1024, 1024),     # bottleneck: 8 n-tiles, 64 K-chunks, ragged 16x32 tiles
+    (1, 1280, 1918, 64, 64),     # BASELINE.json configs[3] (1918x1280), L0: the widest in-image index range
+    (1, 1280, 1918, 128, 64),    # ... its decoder conv on the concat input (pixel pitch 128)
 ]
 
 
@@ -133,19 +135,21 @@ def test_maxpool_full_size():
     assert torch.equal(picked, (dpool != 0).float())
 
 
-def test_unet_full_size_train_step_runs_and_is_finite():
-    """One bf16 training step at the benchmark's image size (batch 2): shapes, finiteness, and the fused loss equals
-    the reference's composition (train.py:102-111) evaluated by torch on the logits the network produced."""
+@pytest.mark.parametrize('n,hh,ww', [(2, 640, 959), (1, 1280, 1918)])
+def test_unet_full_size_train_step_runs_and_is_finite(n, hh, ww):
+    """One bf16 training step at the benchmark's image sizes (BASELINE.json configs[1] and configs[3]): shapes,
+    finiteness, and the fused loss equals the reference's composition (train.py:102-111) evaluated by torch on the
+    logits the network produced."""
     from unet import UNet
     from unetk.loss import segmentation_loss
     from utils.dice_score import dice_loss
     torch.manual_seed(0)
     net = UNet(3, 2, False).cuda().to(memory_format=torch.channels_last).train()
-    img = torch.rand((2, 3, 640, 959), device='cuda').contiguous(memory_format=torch.channels_last)
-    mask = (torch.rand((2, 640, 959), device='cuda') < 0.2).long()
+    img = torch.rand((n, 3, hh, ww), device='cuda').contiguous(memory_format=torch.channels_last)
+    mask = (torch.rand((n, hh, ww), device='cuda') < 0.2).long()
     with torch.autocast('cuda', dtype=torch.bfloat16):
         logits = net(img)
-    assert logits.shape == (2, 2, 640, 959)
+    assert logits.shape == (n, 2, hh, ww)
     loss = segmentation_loss(logits, mask)
     loss.backward()
     lf = logits.detach().float()
@@ -179,3 +183,38 @@ def test_convT_bias_gradient_from_dgrad_sums_exact_on_integers(n, h, w, c):
     db2 = torch.empty_like(db)
     ops.convT2x2_wgrad(x, dcat, c // 2, dw, db2, 0, 0)
     assert torch.equal(db2, ref)
+
+
+def test_bilinear_batch64_inference_fused_epilogue_matches_unfused():
+    """BASELINE.json configs[2]: UNet(bilinear=True).eval(), bf16, batch 64 at 959x640.  The inference path folds
+    eval-mode BatchNorm + ReLU (+ the encoder's max-pool) into the conv epilogue (unetk_conv3x3_fprop_bn_relu); the
+    same net through the unfused kernels (conv -> bn_relu_apply -> maxpool, the bf16 pre-BN tensor materialised as in
+    the reference) must give the same masks and logits within bf16 rounding."""
+    from unet import UNet
+    from unetk import blocks
+    torch.manual_seed(0)
+    net = UNet(3, 2, True).cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    img = torch.rand((64, 3, 640, 959), device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    net.train()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        net(img[:2])                                    # running statistics away from their (0, 1) initial values
+    net.eval()
+    with torch.inference_mode(), torch.autocast('cuda', dtype=torch.bfloat16):
+        fused = net(img)
+        assert blocks.FUSE_EVAL_EPILOGUE
+        blocks.FUSE_EVAL_EPILOGUE = False
+        try:
+            plain = net(img)
+        finally:
+            blocks.FUSE_EVAL_EPILOGUE = True
+    assert fused.shape == (64, 2, 640, 959) and fused.dtype == torch.bfloat16
+    f, p = fused.float(), plain.float()
+    assert torch.isfinite(f).all()
+    assert float((f - p).abs().max() / p.abs().max()) <= 2e-2
+    # where the two classes are further apart than bf16 noise the masks agree; overall agreement stays >= 99.9 %
+    agree = float((f.argmax(1) == p.argmax(1)).float().mean())
+    margin = (p[:, 0] - p[:, 1]).abs()
+    clear = margin > 2e-2 * p.abs().max()
+    assert bool((f.argmax(1) == p.argmax(1))[clear].all())
+    assert agree >= 0.999 or float(clear.float().mean()) < 0.999, agree

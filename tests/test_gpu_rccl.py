@@ -3,7 +3,8 @@ What this can and cannot show: the average over one rank is the identity written
 the bucketed asynchronous path RUNS on RCCL (ReduceOp.AVG on fp32 ranges of the flat gradient buffer, work handles,
 >= 5 buckets per step, hand-over between the stream the C ABI launches on and RCCL's) and leaves the training
 trajectory where the local trainer's is -- to the run-to-run noise of two LOCAL trainers (fp64 BatchNorm atomics
--> last-bit changes -> RMSprop's sign-like normalisation; measured 1.5e-5 on the loss after one step), bar 1e-3.
+-> last-bit changes -> RMSprop's sign-like normalisation; measured 1.5e-5 on the loss after one step): loss within
+1e-3 relative, parameters within 5 % of their own movement.
 It cannot expose a missing stream dependency (a 1-rank all-reduce rewrites what it read).  World sizes > 1 are
 covered on CPU by tests/test_ddp_gloo.py; the 8-GPU run is the driver's."""
 import pytest
@@ -23,6 +24,7 @@ def test_single_rank_rccl_step_equals_local_step():
         a = UNet(3, 2, False).to(dev).to(memory_format=torch.channels_last).train()
         b = UNet(3, 2, False).to(dev).to(memory_format=torch.channels_last).train()
         b.load_state_dict(a.state_dict())
+        p0 = {k: v.detach().clone() for k, v in a.named_parameters()}
         ta = Trainer(a, amp=True)
         tb = Trainer(b, amp=True, bucket_bytes=4 << 20, force_collectives=True)
         assert tb.sync.active and tb.sync.native_avg and not ta.sync.active
@@ -45,9 +47,15 @@ def test_single_rank_rccl_step_equals_local_step():
             n_buckets = count[0]
             assert abs(float(la) - float(lb)) <= 1e-3 * abs(float(la))
         assert n_buckets >= 5                      # 124 MB of gradients in >= 4 MB buckets
+        # three RMSprop steps move every element by ~10 lr per step (sign-like normalisation).  Two LOCAL trainers
+        # differ only where a gradient is at the rounding noise of the fp64-atomic orderings and steps the other
+        # way; the RCCL trainer must stay within that: mean |pa - pb| below 5 % of the mean movement |pa - p0|
+        # (a missing or doubled bucket average would show as a difference of the order of the movement itself)
+        moved, diff = 0.0, 0.0
         for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-            if True:
-                # three RMSprop steps move a weight by at most ~1e-3 (lr 1e-5 x g/sqrt(0.01 g^2) x momentum sum)
-                assert float((pa - pb).abs().max()) < 2e-3, k
+            moved += float((pa - p0[k]).abs().sum())
+            diff += float((pa - pb).abs().sum())
+            assert float((pa - pb).abs().mean()) <= 0.25 * float((pa - p0[k]).abs().mean()) + 1e-9, k
+        assert moved > 0 and diff <= 0.05 * moved, (diff, moved)
     finally:
         dist.destroy_process_group()
