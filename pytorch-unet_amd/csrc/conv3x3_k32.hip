@@ -1,0 +1,885 @@
+// conv3x3 (pad 1, stride 1; fprop, and dgrad with rotated weights) in bf16 on v_mfma_f32_16x16x32_bf16.
+//   unet_parts.py:16,19 (aten::conv2d) and its input gradient.
+//
+// Why this shape.  One 16x16x32 instruction covers K = 32 = the 32 input channels of ONE tap that an LDS pixel row
+// (64 B) holds; for the same output tile per wave it moves the same LDS bytes and takes the same matrix-pipe cycles
+// as the 32x32x16 form, but writes half as many accumulator values per FLOP and the chip holds a higher clock on it
+// (MI355X_MICROARCH.md, DVFS give-back item 7; measured here: +7..9 % on every layer shape).  Its C layout also puts
+// the GEMM-N index on 16 lanes, so with 8 column blocks a lane owns 8 ADJACENT channels of a pixel: 16-byte stores.
+//
+//   GEMM view   M = output pixels, N = output channels, K = 9 taps x input channels
+//   tile        one 512-thread workgroup (8 waves) per CU: 16 x 32 output pixels x BN = 16*NB16 channels
+//               (NB16 = 8: 128 channels; NB16 = 4: 64 channels).  Wave w owns tile rows 2w, 2w+1 = four 16-pixel
+//               A fragments (row mb, pixel set ps) x NB16 column blocks -> acc[2][2][NB16] of 4 registers.
+//   LDS         2 x input halo tile (18 x 34 pixels x 64 B = 32 channels, 39 KiB)  +  2 x weight stage
+//               (NB16 = 8: taps 0-4 / taps 5-8 of the 32-channel chunk, 40 KiB; NB16 = 4: all 9 taps, 36 KiB)
+//   loop        per weight stage: LDS-DMA of the next stage (+ its share of the next input chunk), spread between the
+//               k-steps -> MFMAs of this stage -> s_waitcnt vmcnt(0) + ONE barrier.  The chunk stream runs on across
+//               the tiles a workgroup walks.  64 -> 64 layers (two stages in all): both stages stay resident in the
+//               two weight buffers for the whole workgroup (WRES) -- half the LDS fill traffic.
+//
+// A operand.  Lane (r = l & 15, g = l >> 4) holds row r, k-group g: it reads the 16-byte piece g (8 channels) of
+// pixel pi(r) + 4 ps + tap shift.  Rows map to pixels as pi = {0-3, 16-19, 24-27, 8-11}: a ds_read_b128 is served in
+// the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ..., i.e. rows {0-3,12-15} of one k-group with rows {4-11}
+// of the next; with pi those are pixels {P..P+3, P+8..P+11} on piece a and {P+16.., P+24..} on piece a^1 -- bank rows
+// Q, Q+2, Q+4, Q+6 for every pixel phase, and the image's XOR swizzle (piece ^ (bank row & 3)) then gives 16 distinct
+// 16-byte slots for every tap shift (the natural map pi(r) = r is 2-way conflicted for every swizzle of this form).
+// C layout: column = l & 15 -> channel NB16*c + cb; row = 4*(l >> 4) + reg -> pixel {0,16,24,8}[l >> 4] + reg + 4 ps.
+#include <type_traits>
+
+#ifndef UNETK_K32_SCHED
+#define UNETK_K32_SCHED 1
+#endif
+#ifndef UNETK_K32_CBS
+#define UNETK_K32_CBS 4
+#endif
+#ifndef UNETK_K32_ABL
+#define UNETK_K32_ABL 0      // perf ablations only: 1 no statistics arithmetic, 2 no stores
+#endif
+#ifndef UNETK_K32_STAMP
+#define UNETK_K32_STAMP 0    // diagnostic build: s_memtime stamps around the phases of conv3x3_k32n64_kernel
+#endif
+#ifndef UNETK_K32_LDSSTATS
+#define UNETK_K32_LDSSTATS 0
+#endif
+
+#include "conv_common.h"
+#include "conv_config.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(4))) unsigned frag_t;      // one 16-byte MFMA operand fragment
+
+__device__ uint4 g_zero_page_k32[8];
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1 (the loop index feeds constexpr contexts)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int NB16> __device__ __forceinline__ void store_adjacent(bf16* p, const float (&v)[NB16]) {
+  if constexpr (NB16 == 8) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(p));
+  } else {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(p));
+  }
+}
+
+template <int NB16, bool AFF, bool WRES>
+__global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
+  constexpr int NW = 8, MB = 2, TR = MB * NW, HP = 34, S = 64, NP = 4, TAPS = 9;
+  constexpr int NPIX = (TR + 2) * HP;
+  constexpr int IN_INSTR = (NPIX * NP + 63) / 64;            // 39 one-KiB DMA pieces
+  constexpr int IN_BYTES = IN_INSTR * 1024;
+  constexpr int BN = 16 * NB16;
+  constexpr int NSTAGE = NB16 == 8 ? 2 : 1;                  // weight stages per 32-channel input chunk
+  constexpr int STEPS0 = NB16 == 8 ? 5 : 9;                  // taps of stage 0 (stage 1: the rest)
+  constexpr int W_BYTES = STEPS0 * NB16 * 1024;              // a weight buffer holds the larger stage
+  constexpr int CBS = UNETK_K32_CBS;                         // column blocks per sub-step
+  constexpr int HN = NB16 / CBS;                             // sub-steps per k-step
+  constexpr int IN_PER_WAVE = (IN_INSTR + NW - 1) / NW;      // 5
+  // LDS: [input 0][input 1][weights 0][weights 1]
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+
+  const int nt = blockIdx.x % P.n_tiles;
+  const int grp = blockIdx.x / P.n_tiles;
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const int tile_begin = grp * P.tpb;
+  const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
+  if (tile_begin >= tile_end) return;
+
+  const int nin = P.Cin / 32;                                // 32-channel input chunks
+  const char* wbase = reinterpret_cast<const char*>(P.wpk) + (size_t)nt * nin * (TAPS * NB16 * 1024);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_k32);
+
+  // A-fragment addresses.  This lane's row reads halo pixel p = p00 + rr*HP + col (rr = mb + tap/3 in 0..3, col =
+  // 4 ps + tap%3 in 0..6) at byte (p << 6) + (swz << 4), swz = ((p >> 2) ^ g) & 3.  The linear part is the lane's base
+  // plus a compile-time offset (the ds_read offset field); the 2-bit swizzles of all 4 x 7 pixels are packed into two
+  // registers (field rr*8 + col), so a read costs one v_bfe + one v_lshl_add instead of six VALU instructions --
+  // a 16x16x32 MFMA leaves only two VALU issue slots in its shadow.
+  const int pi = (c16 & 3) + ((c16 >> 2) == 1 ? 16 : (c16 >> 2) == 2 ? 24 : (c16 >> 2) == 3 ? 8 : 0);
+  const int p00 = (MB * wid) * HP + pi;
+  unsigned swz_lo = 0, swz_hi = 0;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int col = 0; col < 7; ++col) {
+      const unsigned v = (unsigned)((((p00 + rr * HP + col) >> 2) ^ g4) & 3);
+      if (rr < 2) swz_lo |= v << (2 * (rr * 8 + col));
+      else swz_hi |= v << (2 * ((rr - 2) * 8 + col));
+    }
+
+  // DMA descriptors of the tile being staged: byte offset of this lane's piece (chunk 0) inside the image (< 4 GiB:
+  // checked by the caller), or ~0u -> zero page
+  unsigned dma_off[IN_PER_WAVE];
+  const char* ximg = nullptr;
+  auto setup_stage = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    ximg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+#pragma unroll
+    for (int f = 0; f < IN_PER_WAVE; ++f) {
+      const int fi = min(f * NW + wid, IN_INSTR - 1);   // surplus slots of the issue grid repeat the last piece
+      const int id = fi * 64 + lane;                     // LDS slot: pixel p, physical piece sl
+      const int p = id / NP, sl = id % NP;
+      const int c = sl ^ ((p >> 2) & (NP - 1));          // logical piece stored in that slot
+      const int hr = p / HP, hc = p - hr * HP;
+      const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+      unsigned off = ~0u;
+      if (p < NPIX && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) off = ((unsigned)(yy * P.W + xx) * P.ldx + c * 8) * 2u;
+      dma_off[f] = off;
+    }
+  };
+  // branch-free DMA issue (a branch inside the MFMA loop ends the basic block and costs a full lgkmcnt(0) wait)
+  auto issue_input = [&](int q, int in_chunk, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, IN_INSTR - 1);
+    // two selects and one 64-bit add (kept branch-free: a branch would split the MFMA block)
+    const bool ok = live && dma_off[q] != ~0u;
+    const char* src = (ok ? ximg : zero) + (ok ? dma_off[q] + (unsigned)in_chunk * 64u : 0u);
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+  // weight fragment q of the stage that starts at fragment `frag0` of chunk `chunk` and has `nfrag` fragments
+  auto issue_weight = [&](int q, int chunk, int frag0, int nfrag, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, nfrag - 1);
+    const char* src = live ? wbase + ((size_t)chunk * (TAPS * NB16) + frag0 + fi) * 1024 + lane * 16 : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+
+  f32x4v acc[MB][2][NB16];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb) acc[mb][ps][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const int ch0 = nt * BN + NB16 * c16;                      // first of this lane's NB16 adjacent channels
+
+  setup_stage(tile_begin);
+  const unsigned lds0 = lds_address(smem);
+  const unsigned ldsw0 = lds0 + 2 * IN_BYTES;
+#pragma unroll
+  for (int q = 0; q < IN_PER_WAVE; ++q) issue_input(q, 0, lds0, true);
+  if constexpr (WRES) {
+    // every stage of the layer fits the two weight buffers (<= 2 stages): loaded once, never refilled
+    const int nst = nin * NSTAGE;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      if (st < nst) {
+        const int chunk = st / NSTAGE, s_in = st % NSTAGE;
+        const int frag0 = s_in == 0 ? 0 : STEPS0 * NB16, nfrag = (s_in == 0 ? STEPS0 : TAPS - STEPS0) * NB16;
+        for (int q = 0; q * NW < nfrag; ++q) issue_weight(q, chunk, frag0, nfrag, ldsw0 + st * W_BYTES, true);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q * NW < STEPS0 * NB16; ++q) issue_weight(q, 0, 0, STEPS0 * NB16, ldsw0, true);
+  }
+  // BN statistics of all tiles of this workgroup: per tile in registers; across tiles in registers too, or (LDSSTATS)
+  // in an LDS array [BN][2] behind the staging buffers by ds_add_f32
+  constexpr bool LDSSTATS = UNETK_K32_LDSSTATS != 0;
+  float* red = reinterpret_cast<float*>(smem + 2 * IN_BYTES + 2 * W_BYTES);
+  float tsum[LDSSTATS ? 1 : NB16], tsq[LDSSTATS ? 1 : NB16];
+  if constexpr (LDSSTATS) {
+    if (tid < 2 * BN) red[tid] = 0.f;      // visible to every wave after the prologue barrier below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) tsum[cb] = tsq[cb] = 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int curi = 0, curw = 0;
+
+  float asc[NB16], ash[NB16];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) { asc[cb] = P.aff_scale[ch0 + cb]; ash[cb] = P.aff_shift[ch0 + cb]; }
+  }
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    for (int ic = 0; ic < nin; ++ic) {
+      // the NEXT input chunk (of this tile, or the first of the next tile) is staged while this one is consumed
+      int next_in = ic + 1;
+      bool live_in = true;
+      if (ic + 1 == nin) {
+        next_in = 0;
+        if (tile + 1 < tile_end) setup_stage(tile + 1);
+        else live_in = false;
+      }
+      const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
+      const char* lds_in = smem + curi * IN_BYTES;
+      auto run_stage = [&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        constexpr int tap0 = st == 0 ? 0 : STEPS0;
+        constexpr int nsteps = st == 0 ? STEPS0 : TAPS - STEPS0;
+        // next weight stage: (ic, st + 1), or stage 0 of the next chunk / of the next tile's first chunk
+        constexpr int nst_in = (st + 1) % NSTAGE;
+        constexpr int nfrag_next = (nst_in == 0 ? STEPS0 : TAPS - STEPS0) * NB16;
+        constexpr int frag0_next = nst_in == 0 ? 0 : STEPS0 * NB16;
+        constexpr int w_pieces = WRES ? 0 : (nfrag_next + NW - 1) / NW;
+        int next_wc = ic;
+        bool live_w = true;
+        if (st + 1 == NSTAGE) {
+          next_wc = ic + 1;
+          if (ic + 1 == nin) {
+            next_wc = 0;
+            live_w = live_w && (tile + 1 < tile_end);
+          }
+        }
+        const int widx = WRES ? ((ic * NSTAGE + st) & 1) : curw;
+        const char* lds_w = smem + 2 * IN_BYTES + widx * W_BYTES;
+        const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
+        // input pieces of this stage: IN_PER_WAVE split over the NSTAGE stages of the chunk
+        constexpr int IN_PER_ST = (IN_PER_WAVE + NSTAGE - 1) / NSTAGE;
+        constexpr int in_q0 = st * IN_PER_ST;
+        constexpr int in_pieces = (st + 1 == NSTAGE) ? IN_PER_WAVE - in_q0 : IN_PER_ST;
+        constexpr int ndma = in_pieces + w_pieces;
+        constexpr int pps = (ndma + nsteps - 1) / nsteps;      // DMA pieces per k-step
+        auto issue_piece = [&](int q) {
+          if (q < in_pieces) issue_input(in_q0 + q, next_in, nbuf_in, live_in);
+          else issue_weight(q - in_pieces, next_wc, frag0_next, nfrag_next, nbuf_w, live_w);
+        };
+
+        {
+          // LDS byte offsets of this stage's buffers, opaque to the optimiser: the fragment reads then keep their
+          // compile-time parts (tap / column-block offsets < 64 KiB) in the instruction's offset field instead of
+          // one v_add per read (the compiler would otherwise specialise the loop per buffer parity)
+          int a_base = (int)lds_address(lds_in) + (p00 << 6), w_base = (int)lds_address(lds_w) + lane * 16;
+          asm volatile("" : "+v"(a_base), "+v"(w_base));
+          const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
+          frag_t fa[2][MB][2], fb[2][CBS];
+          int an[MB][2];                                     // addresses of the NEXT step's A fragments
+          auto a_addrs = [&](int s_next) {
+            const int t = tap0 + s_next;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int ps = 0; ps < 2; ++ps) {
+                const int rr = mb + t / 3, col = 4 * ps + (t % 3);
+                const unsigned sw = __builtin_amdgcn_ubfe(rr < 2 ? swz_lo : swz_hi, 2 * ((rr & 1) * 8 + col), 2);
+                an[mb][ps] = a_base + (int)(sw << 4) + (rr * HP + col) * 64;
+              }
+          };
+          auto load_a = [&](frag_t (&a)[MB][2]) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int ps = 0; ps < 2; ++ps) a[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + an[mb][ps]);
+          };
+          auto load_b = [&](int u, frag_t (&b)[CBS]) {        // sub-step u = s * HN + hh
+#pragma unroll
+            for (int cb = 0; cb < CBS; ++cb)
+              b[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + (u * CBS + cb) * 1024);
+          };
+          a_addrs(0);
+          load_a(fa[0]);
+          load_b(0, fb[0]);
+          if (nsteps > 1) a_addrs(1);
+          static_for<0, nsteps * HN>([&](auto u_c) {
+            {
+              constexpr int u = decltype(u_c)::value, s = u / HN, hh = u % HN;
+              // ---- the LDS reads of the NEXT sub-step first: they have this sub-step's MFMAs to land
+              if (u + 1 < nsteps * HN) load_b(u + 1, fb[(u + 1) & 1]);
+              if (hh == HN - 1 && s + 1 < nsteps) load_a(fa[(s + 1) & 1]);
+#if UNETK_K32_SCHED == 0
+              __builtin_amdgcn_sched_barrier(0);
+#endif
+              // ---- then DMA issue, the addresses of the step after next, and the MFMAs (interleaved by the compiler)
+              if (hh == 0) {
+#pragma unroll
+                for (int q = s * pps; q < (s + 1) * pps && q < ndma; ++q) issue_piece(q);
+              }
+              if (hh == HN - 1 && s + 2 < nsteps) a_addrs(s + 2);
+#pragma unroll
+              for (int cb = 0; cb < CBS; ++cb)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                  for (int ps = 0; ps < 2; ++ps)
+                    acc[mb][ps][hh * CBS + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[s & 1][mb][ps]), __builtin_bit_cast(bf16x8, fb[u & 1][cb]),
+                        acc[mb][ps][hh * CBS + cb], 0, 0, 0);
+#if UNETK_K32_SCHED == 2
+              {
+                // one LDS read behind each of the first MFMAs: the reads of all eight (phase-locked) waves then
+                // spread over the MFMA time instead of arriving at the LDS port as one burst
+                constexpr int nld = ((u + 1 < nsteps * HN) ? CBS : 0) + ((hh == HN - 1 && s + 1 < nsteps) ? 4 : 0);
+#pragma unroll
+                for (int k = 0; k < nld; ++k) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * CBS - nld > 0 ? 4 * CBS - nld : 0, 0);
+              }
+#endif
+              // pin the sub-step: without it the scheduler hoists the LDS reads of several sub-steps ahead and the
+              // 128 accumulators + two fragment sets no longer fit 256 registers (spills inside the MFMA loop)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        }
+        // next stage landed (this wave's DMAs) and every wave is done reading the current buffers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        curw ^= 1;
+      };
+      run_stage(std::integral_constant<int, 0>{});
+      if constexpr (NSTAGE == 2) run_stage(std::integral_constant<int, 1>{});
+      curi ^= 1;
+    }
+
+    // ---- epilogue of this tile: a lane holds, per (row mb, pixel set ps), 4 consecutive pixels x NB16 adjacent channels
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    bf16* yimg = reinterpret_cast<bf16*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+    const int xg = g4 == 1 ? 16 : g4 == 2 ? 24 : g4 == 3 ? 8 : 0;     // pixel of C row 4*g4 within the 32-pixel row
+    const int xl = x0 + xg;
+    const int lane_off = xg * P.ldy + ch0;
+    float ssum[NB16], ssq[NB16];
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) ssum[cb] = ssq[cb] = 0.f;
+    if constexpr (AFF) {
+      // the encoder's MaxPool2d(2) (unet_parts.py:34) of the activation about to be stored: the wave owns tile rows
+      // 2w, 2w+1 and a lane holds 4 horizontally consecutive pixels (first one at a multiple of 4) -- every complete
+      // 2x2 window is four registers of one lane.  max commutes with the (monotone) rounding of the store.
+      if (P.pool != nullptr) {
+        const int yy = y0 + MB * wid;                      // even; the window needs row yy + 1 too
+        bf16* pimg = reinterpret_cast<bf16*>(P.pool) + (size_t)img * (P.H / 2) * (P.W / 2) * P.ldp;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {
+            const int xx = xl + 4 * ps + i;                // even
+            if (yy + 1 < P.H && xx + 1 < P.W) {
+              float pv[NB16];
+#pragma unroll
+              for (int cb = 0; cb < NB16; ++cb) {
+                const float a = fmaxf(fmaf(acc[0][ps][cb][i], asc[cb], ash[cb]), 0.f);
+                const float b = fmaxf(fmaf(acc[0][ps][cb][i + 1], asc[cb], ash[cb]), 0.f);
+                const float c = fmaxf(fmaf(acc[1][ps][cb][i], asc[cb], ash[cb]), 0.f);
+                const float d = fmaxf(fmaf(acc[1][ps][cb][i + 1], asc[cb], ash[cb]), 0.f);
+                pv[cb] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+              }
+              store_adjacent<NB16>(pimg + ((size_t)(yy >> 1) * (P.W / 2) + (xx >> 1)) * P.ldp + ch0, pv);
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int yy = y0 + MB * wid + mb;
+      bf16* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;   // 64-bit arithmetic once per row (wave-uniform)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ri = 4 * ps + i;
+          if (yy < P.H && xl + ri < P.W) {
+            float v[NB16];
+#pragma unroll
+            for (int cb = 0; cb < NB16; ++cb) {
+              if constexpr (AFF) {
+                v[cb] = fmaxf(fmaf(acc[mb][ps][cb][i], asc[cb], ash[cb]), 0.f);
+              } else {
+                const float f = to_f32(from_f32<bf16>(acc[mb][ps][cb][i]));   // statistics of the value as stored
+                v[cb] = f;
+                if (!(UNETK_K32_ABL & 1)) {
+                  ssum[cb] += f;
+                  ssq[cb] += f * f;
+                }
+              }
+            }
+            if (!(UNETK_K32_ABL & 2)) store_adjacent<NB16>(rowp + ri * P.ldy + lane_off, v);
+            else asm volatile("" ::"v"(v[0]), "v"(v[NB16 - 1]));
+          }
+#pragma unroll
+          for (int cb = 0; cb < NB16; ++cb) acc[mb][ps][cb][i] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) {
+      if constexpr (LDSSTATS) {
+        if (!AFF && P.stats != nullptr) {
+          __hip_atomic_fetch_add(red + (NB16 * c16 + cb) * 2, ssum[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(red + (NB16 * c16 + cb) * 2 + 1, ssq[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        tsum[cb] += ssum[cb];
+        tsq[cb] += ssq[cb];
+      }
+    }
+  }
+
+  // ---- one LDS reduction (register statistics) and one set of fp64 atomics per workgroup
+  if (!AFF && P.stats != nullptr) {
+    if constexpr (LDSSTATS) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 2 * BN) {
+        double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+        unsafeAtomicAdd(dst, (double)red[tid]);
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb) {                   // lanes l, l^16, l^32, l^48 hold the same channels
+        tsum[cb] += __shfl_xor(tsum[cb], 16, 64);
+        tsq[cb] += __shfl_xor(tsq[cb], 16, 64);
+        tsum[cb] += __shfl_xor(tsum[cb], 32, 64);
+        tsq[cb] += __shfl_xor(tsq[cb], 32, 64);
+      }
+      float* part = reinterpret_cast<float*>(smem);         // [NW][BN][2]; every DMA landed, every read retired
+      if (g4 == 0) {
+#pragma unroll
+        for (int cb = 0; cb < NB16; ++cb) {
+          part[(wid * BN + NB16 * c16 + cb) * 2 + 0] = tsum[cb];
+          part[(wid * BN + NB16 * c16 + cb) * 2 + 1] = tsq[cb];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 2 * BN) {
+        float v = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += part[w8 * 2 * BN + tid];
+        double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + nt * BN) * 2 + tid;
+        unsafeAtomicAdd(dst, (double)v);
+      }
+    }
+  }
+}
+
+// ================================================================================================================
+// The 64-channel n-tile (GEMM-N = 64: inc.3, up4.0, up4.3 forward; inc.3, up4.3, down1.0 dgrad) with the epilogue
+// taken OFF the critical path.  At K = 576 a tile is only 288 MFMAs per wave, and ablations of the kernel above showed
+// the epilogue (round + statistics arithmetic + 16 stores per lane, all eight waves at once, no MFMA running) costing
+// 40 % of the launch: 0.88 ms with it, 0.52 ms without (64 -> 64 at 16 x 640 x 959).  Here
+//   * the tile's outputs are rounded ONCE into 32 registers of packed bf16 and the accumulators are free again;
+//   * the BatchNorm statistics are taken from the packed values, two pixels per instruction: v_dot2c_f32_bf16(y, 1, sum)
+//     and v_dot2c_f32_bf16(y, y, sumsq) -- exact bf16 products accumulated in fp32, 64 instructions per tile and lane
+//     instead of 64 unpack + 128 add/fma, and they too ride in the shadow of the next tile's MFMAs (a first version
+//     did them as MFMAs -- ones * Y and the diagonal of Y^T * Y -- which was bit-exact as well but cost 32 accumulator
+//     registers, i.e. spills, and 11 % more matrix-pipe time at K = 576);
+//   * the 16 stores of tile i are issued two per k-step under the MFMAs of tile i+1's first stage (EXEC-masked inline
+//     asm: no branch splits the MFMA block), 8 bytes per lane, nontemporal.
+template <bool WRES, bool STATS>
+__global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
+  constexpr int NB16 = 4, NW = 8, MB = 2, TR = MB * NW, HP = 34, NP = 4, TAPS = 9;
+  constexpr int NPIX = (TR + 2) * HP;
+  constexpr int IN_INSTR = (NPIX * NP + 63) / 64;            // 39 one-KiB DMA pieces
+  constexpr int IN_BYTES = IN_INSTR * 1024;
+  constexpr int BN = 64;
+  constexpr int NFRAG = TAPS * NB16;                         // 36 weight fragments per 32-channel chunk
+  constexpr int W_BYTES = NFRAG * 1024;
+  constexpr int IN_PER_WAVE = (IN_INSTR + NW - 1) / NW;      // 5
+  constexpr int W_PER_WAVE = WRES ? 0 : (NFRAG + NW - 1) / NW;
+  constexpr int NDMA = IN_PER_WAVE + W_PER_WAVE;
+  // Every DMA piece of a stage goes out in its first DSTEPS k-steps and the pending stores in the steps after them:
+  // the stores are then the YOUNGEST vector-memory operations of the stage and `s_waitcnt vmcnt(16)` at its end waits
+  // for the DMA only -- the stores complete under the next stage instead of on the barrier.
+  constexpr int DSTEPS = 3;
+  constexpr int PPS = (NDMA + DSTEPS - 1) / DSTEPS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g4 = lane >> 4;
+
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const int tile_begin = blockIdx.x * P.tpb;                 // n_tiles == 1
+  const int tile_end = min(tile_begin + P.tpb, P.N * tiles_per_img);
+  if (tile_begin >= tile_end) return;
+
+  const int nin = P.Cin / 32;
+  const char* wbase = reinterpret_cast<const char*>(P.wpk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_k32);
+
+  const int pi = (c16 & 3) + ((c16 >> 2) == 1 ? 16 : (c16 >> 2) == 2 ? 24 : (c16 >> 2) == 3 ? 8 : 0);
+  const int p00 = (MB * wid) * HP + pi;
+  unsigned swz_lo = 0, swz_hi = 0;                           // see conv3x3_k32_kernel
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int col = 0; col < 7; ++col) {
+      const unsigned v = (unsigned)((((p00 + rr * HP + col) >> 2) ^ g4) & 3);
+      if (rr < 2) swz_lo |= v << (2 * (rr * 8 + col));
+      else swz_hi |= v << (2 * ((rr - 2) * 8 + col));
+    }
+
+  unsigned dma_off[IN_PER_WAVE];
+  const char* ximg = nullptr;
+  auto setup_stage = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    ximg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+#pragma unroll
+    for (int f = 0; f < IN_PER_WAVE; ++f) {
+      const int fi = min(f * NW + wid, IN_INSTR - 1);
+      const int id = fi * 64 + lane;
+      const int p = id / NP, sl = id % NP;
+      const int c = sl ^ ((p >> 2) & (NP - 1));
+      const int hr = p / HP, hc = p - hr * HP;
+      const int yy = y0 + hr - 1, xx = x0 + hc - 1;
+      unsigned off = ~0u;
+      if (p < NPIX && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) off = ((unsigned)(yy * P.W + xx) * P.ldx + c * 8) * 2u;
+      dma_off[f] = off;
+    }
+  };
+  auto issue_input = [&](int q, int in_chunk, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, IN_INSTR - 1);
+    const bool ok = live && dma_off[q] != ~0u;
+    const char* src = (ok ? ximg : zero) + (ok ? dma_off[q] + (unsigned)in_chunk * 64u : 0u);
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+  auto issue_weight = [&](int q, int chunk, unsigned buf, bool live) {
+    const int fi = min(q * NW + wid, NFRAG - 1);
+    const char* src = live ? wbase + ((size_t)chunk * NFRAG + fi) * 1024 + lane * 16 : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+  };
+
+  f32x4v acc[MB][2][NB16];
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  unsigned pk[MB][2][NB16][2];                                // previous tile, rounded: [row][pixel set][channel] x 4 pixels
+  float tsum[NB16], tsq[NB16];                                // per-lane statistics of all tiles of this workgroup
+#pragma unroll
+  for (int cb = 0; cb < NB16; ++cb) tsum[cb] = tsq[cb] = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb) pk[mb][ps][cb][0] = pk[mb][ps][cb][1] = 0u;
+  // where the pending stores go: row bases (wave-uniform), first pixel column of this lane, and the column limit per
+  // row (0 = nothing pending / row outside the image)
+  const bf16* st_row[MB] = {nullptr, nullptr};
+  int st_wlim[MB] = {0, 0};
+  int st_xl = 0;
+  bool st_all16 = false;                                      // every pending store has at least one lane to write
+  const int xg = g4 == 1 ? 16 : g4 == 2 ? 24 : g4 == 3 ? 8 : 0;
+  const unsigned lane_off2 = (unsigned)(xg * P.ldy + NB16 * c16) * 2u;      // byte offset inside a 32-pixel row segment
+
+  // store k = (mb, ps, i) of the pending tile: 4 adjacent channels of one pixel, 8 bytes, nontemporal, EXEC-masked
+  auto emit_store = [&](int k) {
+    const int mb = k >> 3, ps = (k >> 2) & 1, i = k & 3, ri = 4 * ps + i;
+    const unsigned sel = (i & 1) ? 0x07060302u : 0x05040100u;
+    u32x2 d;
+    d[0] = __builtin_amdgcn_perm(pk[mb][ps][1][i >> 1], pk[mb][ps][0][i >> 1], sel);
+    d[1] = __builtin_amdgcn_perm(pk[mb][ps][3][i >> 1], pk[mb][ps][2][i >> 1], sel);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(st_xl + ri < st_wlim[mb]);
+    const unsigned off = lane_off2 + (unsigned)(ri * P.ldy) * 2u;
+    unsigned long long keep;
+    if (UNETK_K32_ABL & 2) {
+      asm volatile("" ::"s"(m), "v"(off), "v"(d), "s"(st_row[mb]));
+      return;
+    }
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "global_store_dwordx2 %2, %3, %4 nt\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(keep)
+        : "s"(m), "v"(off), "v"(d), "s"(st_row[mb])
+        : "memory");
+  };
+
+  // statistics of the pending tile, group g = (mb, ps): 4 channels x 4 pixels = 8 packed registers, 16 instructions.
+  // (pixels outside the image were zeroed when the tile was packed; with nothing pending pk is all zero)
+  auto emit_stats = [&](int g) {
+    const int mb = g >> 1, ps = g & 1;
+    const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bf16x2 y2 = __builtin_bit_cast(bf16x2, pk[mb][ps][cb][e]);
+        tsum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, tsum[cb], false);
+        tsq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, tsq[cb], false);
+      }
+  };
+
+  setup_stage(tile_begin);
+  const unsigned lds0 = lds_address(smem);
+  const unsigned ldsw0 = lds0 + 2 * IN_BYTES;
+#pragma unroll
+  for (int q = 0; q < IN_PER_WAVE; ++q) issue_input(q, 0, lds0, true);
+  {
+    const int nst = WRES ? nin : 1;                           // WRES: every chunk's weights (<= 2), loaded once
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+      if (st < nst)
+        for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, st, ldsw0 + st * W_BYTES, true);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int curi = 0, curw = 0;
+
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};                // stamps: prologue reads, MFMA steps, wait, barrier, hand-over
+  auto run_stage = [&](auto first_c, int tile, int ic) {
+    constexpr bool FIRST = decltype(first_c)::value;         // first chunk of a tile: C = 0, and the pending stores
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (UNETK_K32_STAMP) t0 = __builtin_amdgcn_s_memtime();
+    int next_in = ic + 1;
+    bool live_in = !(UNETK_K32_ABL & 4);
+    if (ic + 1 == nin) {
+      next_in = 0;
+      if (tile + 1 < tile_end) setup_stage(tile + 1);
+      else live_in = false;
+    }
+    int next_wc = ic + 1;
+    bool live_w = !(UNETK_K32_ABL & 4);
+    if (ic + 1 == nin) {
+      next_wc = 0;
+      live_w = tile + 1 < tile_end;
+    }
+    const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
+    const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
+    const int widx = WRES ? (ic & 1) : curw;
+    int a_base = (int)(lds0 + curi * IN_BYTES) + (p00 << 6), w_base = (int)(ldsw0 + widx * W_BYTES) + lane * 16;
+    asm volatile("" : "+v"(a_base), "+v"(w_base));           // keep tap / fragment offsets in the ds_read offset field
+    const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
+    frag_t fa[2][MB][2], fb[2][NB16];
+    int an[MB][2];
+    auto a_addrs = [&](int t) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int rr = mb + t / 3, col = 4 * ps + (t % 3);
+          const unsigned sw = __builtin_amdgcn_ubfe(rr < 2 ? swz_lo : swz_hi, 2 * ((rr & 1) * 8 + col), 2);
+          an[mb][ps] = a_base + (int)(sw << 4) + (rr * HP + col) * 64;
+        }
+    };
+    auto load_ab = [&](int t, frag_t (&a)[MB][2], frag_t (&b)[NB16]) {
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb) b[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + (t * NB16 + cb) * 1024);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) a[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + an[mb][ps]);
+    };
+    a_addrs(0);
+    load_ab(0, fa[0], fb[0]);
+    a_addrs(1);
+    if (UNETK_K32_STAMP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t1 = __builtin_amdgcn_s_memtime();
+    }
+    static_for<0, TAPS>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      // the LDS reads of the NEXT k-step first: they have this step's 16 MFMAs to land
+      if (t + 1 < TAPS) load_ab(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = t * PPS; q < (t + 1) * PPS && q < NDMA; ++q) {
+        if (q < IN_PER_WAVE) issue_input(q, next_in, nbuf_in, live_in);
+        else issue_weight(q - IN_PER_WAVE, next_wc, nbuf_w, live_w);
+      }
+      if (t + 2 < TAPS) a_addrs(t + 2);
+      if constexpr (FIRST && STATS) {
+        if (t < 4 && !(UNETK_K32_ABL & 1)) emit_stats(t);     // before the group's stores: pk is read-only, any order
+      }
+      if constexpr (FIRST) {
+        // 16 stores of the previous tile: 3, 3, 3, 3, 2, 2 over the k-steps behind the DMA
+        constexpr int k0 = t < DSTEPS ? 16 : (t - DSTEPS) * 3 - (t - DSTEPS > 4 ? t - DSTEPS - 4 : 0);
+        constexpr int k1 = t < DSTEPS ? 16 : (t + 1 - DSTEPS) * 3 - (t + 1 - DSTEPS > 4 ? t + 1 - DSTEPS - 4 : 0);
+#pragma unroll
+        for (int k = k0; k < k1 && k < 16; ++k) emit_store(k);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const f32x4v c_in = (FIRST && t == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
+            acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, fa[t & 1][mb][ps]), __builtin_bit_cast(bf16x8, fb[t & 1][cb]), c_in, 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // next stage landed (this wave's DMAs) and every wave is done reading the current buffers.  The 16 stores may stay
+    // in flight -- but only when each of them really was a vector-memory operation with a lane to write (a store whose
+    // EXEC mask is empty must not be relied on to count)
+    if (UNETK_K32_STAMP) {
+      t2 = __builtin_amdgcn_s_memtime();
+      if (FIRST && st_all16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      t3 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      t4 = __builtin_amdgcn_s_memtime();
+      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+    } else if (FIRST && st_all16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    curw ^= 1;
+    curi ^= 1;
+  };
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    run_stage(std::true_type{}, tile, 0);
+    for (int ic = 1; ic < nin; ++ic) run_stage(std::false_type{}, tile, ic);
+
+    // ---- hand the tile over: round, statistics, remember where it goes.  Its stores ride under the next tile.
+    unsigned long long th = 0;
+    if (UNETK_K32_STAMP) th = __builtin_amdgcn_s_memtime();
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    const bf16* yimg = reinterpret_cast<const bf16*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+    st_xl = x0 + xg;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int yy = y0 + MB * wid + mb;
+      st_row[mb] = yimg + (size_t)(yy * P.W + x0) * P.ldy;
+      st_wlim[mb] = yy < P.H ? P.W : 0;
+    }
+    st_all16 = (y0 + MB * wid + 1 < P.H) && (x0 + 8 <= P.W);
+    const bool ragged = (y0 + TR > P.H) || (x0 + 32 > P.W);  // wave-uniform: edge tiles mask what lies outside
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int cb = 0; cb < NB16; ++cb) {
+          f32x4v a = acc[mb][ps][cb];
+          if (STATS && ragged) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = (st_xl + 4 * ps + i < st_wlim[mb]) ? a[i] : 0.f;
+          }
+          bf16x2 lo = {(bf16)a[0], (bf16)a[1]}, hi = {(bf16)a[2], (bf16)a[3]};
+          pk[mb][ps][cb][0] = __builtin_bit_cast(unsigned, lo);
+          pk[mb][ps][cb][1] = __builtin_bit_cast(unsigned, hi);
+        }
+    if (UNETK_K32_STAMP) {
+      asm volatile("" ::"v"(pk[1][1][NB16 - 1][1]));
+      ph[4] += __builtin_amdgcn_s_memtime() - th;
+    }
+  }
+  if (UNETK_K32_STAMP && P.stamps != nullptr && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + q] = ph[q];
+    P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + 5] = tile_end - tile_begin;
+    P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  }
+  // the last tile's statistics and stores
+  if constexpr (STATS) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) emit_stats(g);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) emit_store(k);
+
+  if (STATS && P.stats != nullptr) {
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) {                     // lanes l, l^16, l^32, l^48 hold the same channels
+      tsum[cb] += __shfl_xor(tsum[cb], 16, 64);
+      tsq[cb] += __shfl_xor(tsq[cb], 16, 64);
+      tsum[cb] += __shfl_xor(tsum[cb], 32, 64);
+      tsq[cb] += __shfl_xor(tsq[cb], 32, 64);
+    }
+    float* part = reinterpret_cast<float*>(smem);            // [NW][BN][2]; every DMA landed, every read retired
+    if (g4 == 0) {
+#pragma unroll
+      for (int cb = 0; cb < NB16; ++cb) {
+        part[(wid * BN + NB16 * c16 + cb) * 2 + 0] = tsum[cb];
+        part[(wid * BN + NB16 * c16 + cb) * 2 + 1] = tsq[cb];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 2 * BN) {
+      float v = 0;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) v += part[w8 * 2 * BN + tid];
+      double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout) * 2 + tid;
+      unsafeAtomicAdd(dst, (double)v);
+    }
+  }
+}
+
+template <bool WRES, bool STATS> int launch_k32n64(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024);
+  UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<WRES, STATS>), lds);
+  ConvParams Q = P;
+  Q.tiles_x = host_cdiv(P.W, 32);
+  Q.tiles_y = host_cdiv(P.H, 16);
+  Q.n_tiles = 1;
+  const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
+  const int nstages = P.Cin / 32;
+  int tpb = 1;
+  {
+    double best = 1e30;                                       // whole rounds of 256 workgroups (see launch_k32)
+    for (int t = 1; t <= 16; ++t) {
+      const long wgs = (ntiles + t - 1) / t;
+      const long rounds = (wgs + 255) / 256;
+      const double cost = (double)rounds * ((double)t * nstages + 1.5);
+      if (cost < best * 0.999) { best = cost; tpb = t; }
+    }
+  }
+  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  Q.tpb = tpb;
+  const long nblk = (ntiles + tpb - 1) / tpb;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  if (UNETK_K32_STAMP) {   // diagnostic build: UNETK_STAMP_PTR = device buffer of nblk * 8 waves * 8 u64
+    const char* e = getenv("UNETK_STAMP_PTR");
+    Q.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+  }
+  hipLaunchKernelGGL((conv3x3_k32n64_kernel<WRES, STATS>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+template <int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * (39 * 1024) + 2 * ((NB16 == 8 ? 5 : 9) * NB16 * 1024) + 2 * 16 * NB16 * sizeof(float);
+  UNETK_ALLOW_LDS((conv3x3_k32_kernel<NB16, AFF, WRES>), lds);
+  ConvParams Q = P;
+  Q.tiles_x = host_cdiv(P.W, 32);
+  Q.tiles_y = host_cdiv(P.H, 16);
+  const long ntiles = (long)P.N * Q.tiles_y * Q.tiles_x;
+  const int nstages = (P.Cin / 32) * (NB16 == 8 ? 2 : 1);
+  Q.n_tiles = P.Cout / (16 * NB16);
+  // One workgroup per CU is resident, so a launch runs in ROUNDS of 256 workgroups and a partly filled last round is
+  // idle CUs.  Tiles per workgroup: the value that minimises rounds x (tiles x stages per tile + ~1.5 stages of
+  // prologue/epilogue)  (measured sweep: DESIGN.md 2.1).
+  int tpb = 1;
+  {
+    double best = 1e30;
+    for (int t = 1; t <= 16; ++t) {
+      const long wgs = ((ntiles + t - 1) / t) * Q.n_tiles;
+      const long rounds = (wgs + 255) / 256;
+      const double cost = (double)rounds * ((double)t * nstages + 1.5);
+      if (cost < best * 0.999) { best = cost; tpb = t; }
+    }
+  }
+  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  Q.tpb = tpb;
+  Q.dbg = 0;
+  const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
+  if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
+  hipLaunchKernelGGL((conv3x3_k32_kernel<NB16, AFF, WRES>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+}  // namespace
+
+int unetk_internal_conv3x3_k32(const void* params, void* stream) {
+  const ConvParams& P = *static_cast<const ConvParams*>(params);
+  hipStream_t s = (hipStream_t)stream;
+  if (P.Cin % 32 != 0 || P.Cout % 64 != 0) return UNETK_ERR_SHAPE;
+  const int nb16 = conv3_k32_nb16(P.Cout);
+  const bool aff = P.aff_scale != nullptr;
+  if (nb16 == 8) return aff ? launch_k32<8, true, false>(P, s) : launch_k32<8, false, false>(P, s);
+  const bool wres = P.Cin <= 64;                            // <= 2 weight stages: resident in the two buffers
+  static const int nopipe = getenv("UNETK_K32_NOPIPE") ? atoi(getenv("UNETK_K32_NOPIPE")) : 0;
+  if (!aff && P.Cout == 64 && !nopipe) {
+    if (P.stats != nullptr) return wres ? launch_k32n64<true, true>(P, s) : launch_k32n64<false, true>(P, s);
+    return wres ? launch_k32n64<true, false>(P, s) : launch_k32n64<false, false>(P, s);
+  }
+  if (aff) return wres ? launch_k32<4, true, true>(P, s) : launch_k32<4, true, false>(P, s);
+  return wres ? launch_k32<4, false, true>(P, s) : launch_k32<4, false, false>(P, s);
+}

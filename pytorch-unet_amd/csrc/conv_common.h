@@ -4,13 +4,46 @@
 
 namespace {
 
+struct ConvParams {
+  const void* x;
+  const void* wpk;
+  void* y;
+  const float* bias;
+  const float* aff_scale;   // conv3x3 AFF instantiations: y = relu(scale[c] * conv + shift[c]) (eval-mode BatchNorm2d + ReLU)
+  const float* aff_shift;
+  void* pool;                // AFF only: MaxPool2d(2) of the stored activation [N][H/2][W/2][Cout] with pitch ldp, or NULL
+  int ldp;
+  double* stats;
+  int N, H, W;       // tile grid domain (CONV3: image; PWT/CTD: the low-res grid)
+  int Cin, Cout;     // GEMM K channels per tap, GEMM N channels
+  int ldx, ldy, xoff, yoff;
+  int Hs, Ws;        // PWT: destination image; CTD: source (dy) image
+  int padT, padL;
+  int Co;            // PWT: channels of the up-sampled half (Cout == 4*Co)
+  int tiles_x, tiles_y, n_tiles;
+  int tpb;           // spatial tiles per workgroup
+  int nblk;          // workgroups that have work (first-generation kernel: the grid is padded to a multiple of 8)
+  unsigned long long* stamps;   // diagnostic builds only (UNETK_K32_STAMP): per (workgroup, wave) phase cycle sums
+  int dbg;           // ablation flags (UNETK_CONV_DBG): 1 no DMA, 2 no MFMA loop, 4 no stores
+};
+
 // One k-step: a 16-byte A piece and a 16-byte B piece per lane.
 //   bf16: one v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8h..8h+7)
 //   fp32: four v_mfma_f32_32x32x2_f32 (lane half h holds k = 4h+e for e = 0..3) -- exact fp32, fmaf-chain numerics
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
   static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
+#ifdef UNETK_EXP_MFMA16
+    // PERF PROBE ONLY (wrong numerics): the same fragments, FLOPs and matrix-pipe cycles as one 32x32x16 through two
+    // 16x16x32 instructions -- does the chip hold a higher clock on that shape (MI355X_MICROARCH DVFS item 7)?
+    f32x4 c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = c0[i]; c[4 + i] = c1[i]; }
+#else
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
   }
 };
 template <> struct Mma<float> {
@@ -45,3 +78,8 @@ template <typename T, int NB> __device__ __forceinline__ void store_channels(T* 
 }
 
 }  // namespace
+
+// conv3x3_k32.hip: the bf16 conv3x3 kernel on v_mfma_f32_16x16x32_bf16 (K = 32 input channels of one tap per
+// instruction); reads the "k32" packed weight format (conv_config.h).  Same parameter block as the kernels of
+// conv_igemm.hip, which dispatches to it.
+int unetk_internal_conv3x3_k32(const void* params, void* stream);

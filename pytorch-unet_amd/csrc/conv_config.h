@@ -13,6 +13,24 @@ static inline Conv3Config conv3_config(int n_gemm) {
   return {2, 2};
 }
 
+// bf16 conv3x3 (fprop and dgrad) runs on v_mfma_f32_16x16x32_bf16 with its own packed weight format ("k32"):
+//   fragment ((nt * K/32 + kc) * 9 + tap) * NB16 + cb, 1 KiB: lane (c = l & 15, g = l >> 4) holds the 8 GEMM-K channels
+//   kc*32 + 8g .. 8g+7 of GEMM-N channel nt*16*NB16 + NB16*c + cb  (the NB16 channels of one lane are adjacent: the
+//   epilogue stores 16-byte / 8-byte vectors).  NB16 = 8 (128-channel n-tiles) when GEMM-N allows, else 4.
+// The packer and the dispatch both ask conv3_use_k32(), so the format always matches the kernel.
+static inline bool conv3_use_k32(int dtype_is_bf16, int n_gemm) {
+  // UNETK_CONV_K32: 0 never, 2 every bf16 layer, default (1) the 64-channel n-tiles only -- measured: the 64-channel
+  // kernel gains 8-25 % from the shape and its restructured epilogue; for 128-channel tiles (128 accumulator registers
+  // + two fragment sets at the 256-register limit) hipcc's allocation of the 16x16x32 loop only ties the 32x32x16 one
+  static const int mode = getenv("UNETK_CONV_K32") ? atoi(getenv("UNETK_CONV_K32")) : 1;
+  if (!dtype_is_bf16 || mode == 0) return false;
+  return mode == 2 || n_gemm % 128 != 0;
+}
+static inline int conv3_k32_nb16(int n_gemm) {
+  static const int force_nb = getenv("UNETK_CONV_NB") ? atoi(getenv("UNETK_CONV_NB")) : 0;
+  return (n_gemm % 128 == 0 && force_nb != 2) ? 8 : 4;
+}
+
 // ConvTranspose2d k2 s2 forward / dgrad (pointwise GEMMs): 128-channel n-tiles (NB = 4, the double-buffered kernel)
 // whenever GEMM-N allows, else the 64-channel first-generation kernel.  n_gemm = 4*c_out (forward), c_in (dgrad).
 static inline int pw_nb(int n_gemm) {

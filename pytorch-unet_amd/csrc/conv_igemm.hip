@@ -26,27 +26,6 @@
 
 namespace {
 
-struct ConvParams {
-  const void* x;
-  const void* wpk;
-  void* y;
-  const float* bias;
-  const float* aff_scale;   // conv3x3 AFF instantiations: y = relu(scale[c] * conv + shift[c]) (eval-mode BatchNorm2d + ReLU)
-  const float* aff_shift;
-  void* pool;                // AFF only: MaxPool2d(2) of the stored activation [N][H/2][W/2][Cout] with pitch ldp, or NULL
-  int ldp;
-  double* stats;
-  int N, H, W;       // tile grid domain (CONV3: image; PWT/CTD: the low-res grid)
-  int Cin, Cout;     // GEMM K channels per tap, GEMM N channels
-  int ldx, ldy, xoff, yoff;
-  int Hs, Ws;        // PWT: destination image; CTD: source (dy) image
-  int padT, padL;
-  int Co;            // PWT: channels of the up-sampled half (Cout == 4*Co)
-  int tiles_x, tiles_y, n_tiles;
-  int tpb;           // spatial tiles per workgroup
-  int nblk;          // workgroups that have work (first-generation kernel: the grid is padded to a multiple of 8)
-  int dbg;           // ablation flags (UNETK_CONV_DBG): 1 no DMA, 2 no MFMA loop, 4 no stores
-};
 
 template <int MODE> struct Geo;
 template <> struct Geo<0> { static constexpr int TAPS = 9, KS = 2, NPIX = 10 * 34, OUTER = 1; };
@@ -940,6 +919,8 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     // below still serves the transposed-conv modes whose GEMM-N is not a multiple of 128
     const Conv3Config cfg = conv3_config(P.Cout);
     if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+    // bf16: the 16x16x32 kernel (conv3x3_k32.hip) and its weight format; the packer asks the same function
+    if (conv3_use_k32(dtype == UNETK_BF16, P.Cout)) return unetk_internal_conv3x3_k32(&P, s);
     if (P.aff_scale != nullptr) {     // inference epilogue (bf16 only: BASELINE.json configs[2])
       if (dtype != UNETK_BF16) return UNETK_ERR_DTYPE;
       return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2, true>(P, s) : launch_db<bf16, 2, 2, 8, 2, 2, true>(P, s);

@@ -7,27 +7,51 @@
 
 namespace {
 
-struct PackGeo { int N, K, taps, KS, outer, NB; };
+// fmt 0: the 32x32x16 fragment stream described above.  fmt 1 ("k32", bf16 conv3x3, conv_config.h): fragment
+// ((nt*K/32 + kc)*9 + tap)*NB + cb; lane (c = l&15, g = l>>4) holds GEMM-K channels kc*32 + 8g + e of GEMM-N channel
+// nt*16*NB + NB*c + cb (NB = 8 or 4 column blocks of 16).
+struct PackGeo { int N, K, taps, KS, outer, NB, fmt; };
 
-bool pack_geo(int kind, int c_out, int c_in, PackGeo* g) {
+bool pack_geo(int kind, int c_out, int c_in, int dtype, PackGeo* g) {
   switch (kind) {
-    case 0: { const Conv3Config c = conv3_config(c_out); *g = {c_out, c_in, 9, c.KS, 1, c.NB}; return true; }
-    case 1: { const Conv3Config c = conv3_config(c_in); *g = {c_in, c_out, 9, c.KS, 1, c.NB}; return true; }
-    case 2: *g = {4 * c_out, c_in, 1, 4, 1, pw_nb(4 * c_out)}; return true;
-    case 3: *g = {c_in, c_out, 1, 4, 4, pw_nb(c_in)}; return true;
+    case 0:
+      if (conv3_use_k32(dtype == UNETK_BF16, c_out)) { *g = {c_out, c_in, 9, 2, 1, conv3_k32_nb16(c_out), 1}; return true; }
+      { const Conv3Config c = conv3_config(c_out); *g = {c_out, c_in, 9, c.KS, 1, c.NB, 0}; return true; }
+    case 1:
+      if (conv3_use_k32(dtype == UNETK_BF16, c_in)) { *g = {c_in, c_out, 9, 2, 1, conv3_k32_nb16(c_in), 1}; return true; }
+      { const Conv3Config c = conv3_config(c_in); *g = {c_in, c_out, 9, c.KS, 1, c.NB, 0}; return true; }
+    case 2: *g = {4 * c_out, c_in, 1, 4, 1, pw_nb(4 * c_out), 0}; return true;
+    case 3: *g = {c_in, c_out, 1, 4, 4, pw_nb(c_in), 0}; return true;
   }
   return false;
 }
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int kind, int c_out, int c_in, int N,
-                            int K, int taps, int KS, int outer, int NB, long npieces) {
+                            int K, int taps, int KS, int outer, int NB, int fmt, long npieces) {
   constexpr int E = ElemTraits<T>::E;
   const int CH = 2 * KS * E;
   const int nchunks = K / CH;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npieces; idx += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     long f = idx >> 6;
+    if (fmt == 1) {                       // k32 (bf16 conv3x3): kinds 0 and 1 only
+      const int cb = (int)(f % NB); f /= NB;
+      const int tap = (int)(f % 9); f /= 9;
+      const int kc = (int)(f % (K / 32)); f /= (K / 32);
+      const int nt = (int)f;
+      const int c = lane & 15, g = lane >> 4;
+      const int o = nt * 16 * NB + NB * c + cb;
+      T out[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int i = kc * 32 + g * 8 + e;
+        const long sidx = kind == 0 ? ((long)o * c_in + i) * 9 + tap : ((long)i * c_in + o) * 9 + (8 - tap);
+        out[e] = from_f32<T>(src[sidx]);
+      }
+      *reinterpret_cast<uint4*>(dst + idx * E) = *reinterpret_cast<const uint4*>(out);
+      continue;
+    }
     const int nb = (int)(f % NB); f /= NB;
     const int ks = (int)(f % KS); f /= KS;
     const int tap_in = (int)(f % taps); f /= taps;
@@ -60,7 +84,8 @@ struct PlanItem {
   long long piece_begin;     // first UNIT (64 groups; a group = all taps' pieces of one 16-byte K run) of this entry
   int kind, c_out, c_in, dtype;
   int N, K, taps, KS, outer, NB;
-  int pad_[2];
+  int fmt;
+  int pad_[1];
 };
 static_assert(sizeof(PlanItem) % 8 == 0, "plain layout");
 
@@ -96,6 +121,23 @@ template <typename T>
 __device__ __forceinline__ void stage_kind0(const PlanItem& it, long unit, int lane, float* rows) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int RUN = 2 * E * 9, NQ = RUN / 4, RP = RUN + 1;
+  if (it.fmt == 1) {
+    // k32: unit = (nt, kc, cb): 16 channels o, each a contiguous run of 32 input channels x 9 taps = 288 floats
+    constexpr int RUN1 = 288, NQ1 = RUN1 / 4, RP1 = RUN1 + 1;
+    const int nch = it.K / 32;
+    long f1 = unit;
+    const int cb = (int)(f1 % it.NB); f1 /= it.NB;
+    const int kc = (int)(f1 % nch); f1 /= nch;
+    const int nt = (int)f1;
+    for (int q = lane; q < 16 * NQ1; q += 64) {
+      const int r = q / NQ1, c = q - r * NQ1;
+      const int o = nt * 16 * it.NB + it.NB * r + cb;
+      const float4 v = *reinterpret_cast<const float4*>(it.src + ((long)o * it.c_in + kc * 32) * 9 + 4 * c);
+      float* d = rows + r * RP1 + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    return;
+  }
   const int nchunks = it.K / (2 * it.KS * E);
   long f = unit;
   const int nb = (int)(f % it.NB); f /= it.NB;
@@ -119,6 +161,53 @@ __device__ __forceinline__ void emit_unit(const PlanItem& it, long unit, int lan
   const int CH = 2 * it.KS * E;
   const int nchunks = it.K / CH;
   const int ntap = it.taps * it.outer;
+  if (it.fmt == 1) {
+    const int nch = it.K / 32;
+    if (it.kind == 0) {
+      long f = unit;
+      const int cb = (int)(f % it.NB); f /= it.NB;
+      const int kc = (int)(f % nch); f /= nch;
+      const int nt = (int)f;
+      const int c = lane & 15, g = lane >> 4;
+      const float* row = rows + c * 289 + g * 8 * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        T out[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = from_f32<T>(row[e * 9 + t]);
+        const long frag = (((long)nt * nch + kc) * 9 + t) * it.NB + cb;
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + (frag * 64 + lane) * E) =
+            *reinterpret_cast<const uint4*>(out);
+      }
+    } else {
+      // kind 1: unit = 64 consecutive GEMM-N channels o x (kc, k-group g); adjacent lanes read adjacent 36-byte runs
+      long f = unit;
+      const int g = (int)(f & 3); f >>= 2;
+      const int kc = (int)(f % nch); f /= nch;
+      const int o = (int)f * 64 + lane;
+      const int bn = 16 * it.NB;
+      const int nt = o / bn, oin = o - nt * bn;
+      const int c = oin / it.NB, cb = oin - c * it.NB;
+      const int i0 = kc * 32 + g * 8;
+      float v[E][9];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float* p = it.src + ((long)(i0 + e) * it.c_in + o) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[e][t] = p[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        T out[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[e] = from_f32<T>(v[e][8 - t]);      // dgrad: rotated kernel
+        const long frag = (((long)nt * nch + kc) * 9 + t) * it.NB + cb;
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(it.dst) + (frag * 64 + g * 16 + c) * E) =
+            *reinterpret_cast<const uint4*>(out);
+      }
+    }
+    return;
+  }
   if (it.kind == 1) {
     long f = unit;
     const int h = (int)(f & 1); f >>= 1;
@@ -232,11 +321,11 @@ int64_t unetk_pack_plan_build(const unetk_pack_item* items, int n_items, void* p
     if (reinterpret_cast<uintptr_t>(u.dst) & 15) return UNETK_ERR_ALIGN;
     if (u.kind == 0 && (reinterpret_cast<uintptr_t>(u.src) & 15)) return UNETK_ERR_ALIGN;   // 16-byte loads of the runs
     PackGeo g;
-    pack_geo(u.kind, u.c_out, u.c_in, &g);
+    pack_geo(u.kind, u.c_out, u.c_in, u.dtype, &g);
     PlanItem p{};
     p.src = u.src; p.dst = u.dst; p.piece_begin = total;
     p.kind = u.kind; p.c_out = u.c_out; p.c_in = u.c_in; p.dtype = u.dtype;
-    p.N = g.N; p.K = g.K; p.taps = g.taps; p.KS = g.KS; p.outer = g.outer; p.NB = g.NB;
+    p.N = g.N; p.K = g.K; p.taps = g.taps; p.KS = g.KS; p.outer = g.outer; p.NB = g.NB; p.fmt = g.fmt;
     plan[i] = p;
     total += bytes / 16 / (g.taps * g.outer) / 64;   // units: one wave each
   }
@@ -260,8 +349,8 @@ const char* unetk_arch(void) { return "gfx950"; }
 
 int64_t unetk_packed_weight_bytes(int kind, int c_out, int c_in, int dtype) {
   PackGeo g;
-  if (!pack_geo(kind, c_out, c_in, &g)) return UNETK_ERR_ARG;
   if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!pack_geo(kind, c_out, c_in, dtype, &g)) return UNETK_ERR_ARG;
   const int es = dtype == UNETK_BF16 ? 2 : 4;
   const int CH = 2 * g.KS * (16 / es);
   if (c_out <= 0 || c_in <= 0 || g.N % 64 || g.K % CH) return UNETK_ERR_SHAPE;
@@ -274,15 +363,15 @@ int unetk_pack_weight(int kind, const float* src, void* dst, int c_out, int c_in
   if (!src || !dst) return UNETK_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(dst) & 15) return UNETK_ERR_ALIGN;
   PackGeo g;
-  pack_geo(kind, c_out, c_in, &g);
+  pack_geo(kind, c_out, c_in, dtype, &g);
   const long npieces = bytes / 16;
   const int grid = (int)((npieces + 255) / 256 > 4096 ? 4096 : (npieces + 255) / 256);
   if (dtype == UNETK_BF16)
     hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, kind, c_out,
-                       c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, npieces);
+                       c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, g.fmt, npieces);
   else
     hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, kind,
-                       c_out, c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, npieces);
+                       c_out, c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, g.fmt, npieces);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
