@@ -313,7 +313,7 @@ def main(argv=None):
                 # taken on, with their source
                 tr = committed_profile('*_conv_traffic.json', lambda d: d.get('hbm_bytes_per_launch'))
                 mb = committed_profile('*_mfma_util.json',
-                                       lambda d: d.get('conv3x3_db_kernel', {}).get('mfma_busy_fraction'))
+                                       lambda d: (d.get('conv3x3_fprop_dgrad') or d.get('conv3x3_db_kernel', {})).get('mfma_busy_fraction'))
                 if tr:
                     roofline['traffic'] = tr['value']
                     roofline['traffic_source'] = tr['source']

@@ -805,6 +805,41 @@ __global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
           const int to_row_end = P.W - xb;                                   // pixels left in this low-res row
           const int wrap_rows = 2 + ((yb + 1 >= P.H) ? P.Hs - 2 * P.H : 0);    // up-sampled rows to the next low-res row
           const int wrap_off = (wrap_rows * P.Ws - 2 * P.W) * P.ldy;          // element offset added after the wrap
+          if constexpr (sizeof(T) == 2) {
+            // 16-byte stores: this kernel is bound by the store path, which retires wave-instructions rather than
+            // bytes (8-byte stores: ~7 B/clk/CU).  Lanes j and j^1 own the channel groups 4j.. and 4j+4.. of the same
+            // tap; they swap every other pixel (DPP quad_perm [1,0,3,2]) so that the even lane stores 8 adjacent
+            // channels of the even-numbered rows of the block and the odd lane of the odd-numbered ones.
+            const bool odd = (j & 1) != 0;
+            T* dstp = dst0 - (odd ? 4 : 0);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+              unsigned d[2][2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                bf16x2 lo = {(bf16)(acc[mb][0][i + e] + bias[0]), (bf16)(acc[mb][1][i + e] + bias[1])};
+                bf16x2 hi = {(bf16)(acc[mb][2][i + e] + bias[2]), (bf16)(acc[mb][3][i + e] + bias[3])};
+                d[e][0] = __builtin_bit_cast(unsigned, lo);
+                d[e][1] = __builtin_bit_cast(unsigned, hi);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i + e] = 0.f;
+              }
+              unsigned o[4];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                const unsigned give = odd ? d[0][q] : d[1][q];
+                const unsigned r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give, 0xB1, 0xF, 0xF, false);
+                o[q] = odd ? r : d[0][q];
+                o[2 + q] = odd ? d[1][q] : r;
+              }
+              const int row = (i & 3) + 8 * (i >> 2) + 4 * h + (odd ? 1 : 0);
+              const int off = 2 * row * P.ldy + (row >= to_row_end ? wrap_off : 0);
+              typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+              if (!(P.dbg & 4))
+                __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<u32x4*>(dstp + off));
+            }
+            continue;
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;

@@ -18,7 +18,7 @@ def main():
     db, out = sys.argv[1:3]
     c = sqlite3.connect(db)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    fam = r'(conv3x3_db_kernel|wgrad4_bf16_kernel|wgrad3_bf16_kernel|pw_db_kernel|wgrad_bf16_kernel)'
+    fam = r'(conv3x3_db_kernel|conv3x3_k32n64_kernel|conv3x3_k32_kernel|wgrad4_bf16_kernel|wgrad3_bf16_kernel|pw_db_kernel|wgrad_bf16_kernel)'
     for name, cn, v in c.execute('select kernel_name, counter_name, value from counters_collection'):
         m = re.search(fam, name)
         if m:
@@ -32,6 +32,16 @@ def main():
                   'mfma_busy_fraction': avg('SQ_VALU_MFMA_BUSY_CYCLES') / (gui * 256 * 4),
                   'flop_per_cycle': avg('SQ_INSTS_VALU_MFMA_MOPS_BF16') * 512 / gui,
                   'fraction_of_at_clock_peak': avg('SQ_INSTS_VALU_MFMA_MOPS_BF16') * 512 / gui / (1024 * 1017.0)}
+    # the conv3x3 fprop + dgrad family as bench.py's roofline object means it: every instantiation, launch-weighted
+    conv = [v for k, v in res.items() if k.startswith('conv3x3_')]
+    if conv:
+        n = sum(v['launches'] for v in conv)
+        cyc = sum(v['cycles_per_launch'] * v['launches'] for v in conv)
+        res['conv3x3_fprop_dgrad'] = {
+            'launches': n, 'cycles_per_launch': cyc / n,
+            'mfma_busy_fraction': sum(v['mfma_busy_fraction'] * v['cycles_per_launch'] * v['launches'] for v in conv) / cyc,
+            'fraction_of_at_clock_peak': sum(v['fraction_of_at_clock_peak'] * v['cycles_per_launch'] * v['launches']
+                                             for v in conv) / cyc}
     with open(out, 'w') as f:
         json.dump(res, f, indent=1)
     for k, v in res.items():

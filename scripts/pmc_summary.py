@@ -31,11 +31,11 @@ def short(name):
         start = m.end()
         base = name[start:start + int(m.group(1))]
         rest = name[start + int(m.group(1)):]
-        targs = re.match(r'I(DF16b|f)((?:L[ib]\d+E)*)E', rest)
+        targs = re.match(r'I(DF16b|f)?((?:L[ib]\d+E)*)E', rest)
         if targs:
-            dt = 'bf16' if targs.group(1) == 'DF16b' else 'float'
+            dt = {'DF16b': ['bf16'], 'f': ['float'], None: []}[targs.group(1)]
             ints = re.findall(r'L[ib](\d+)E', targs.group(2))
-            return f"{base}<{', '.join([dt] + ints)}>"
+            return f"{base}<{', '.join(dt + ints)}>"
         return base
     return name.split('(')[0]
 
@@ -60,10 +60,10 @@ def main():
         f.write('kernel,launches,read_bytes_per_launch(2xFETCH_SIZE),write_bytes_per_launch(WRITE_SIZE),total_GB_all_launches\n')
         for k, n, fb, wb in rows:
             f.write(f'"{k}",{n},{fb:.0f},{wb:.0f},{(fb + wb) * n / 1e9:.3f}\n')
-    conv = [r for r in rows if r[0].startswith('conv3x3_db_kernel')]
+    conv = [r for r in rows if r[0].startswith(('conv3x3_db_kernel', 'conv3x3_k32n64_kernel', 'conv3x3_k32_kernel'))]
     n = sum(r[1] for r in conv)
     tot = sum((r[2] + r[3]) * r[1] for r in conv)
-    out = {'kernel': 'conv3x3_db_kernel (all instantiations: fprop + dgrad launches)', 'launches': n,
+    out = {'kernel': 'conv3x3_db_kernel + conv3x3_k32n64_kernel (all instantiations: fprop + dgrad launches)', 'launches': n,
            'hbm_bytes_per_launch': tot / max(n, 1),
            'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 '
                      '--warmup 1`; bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: 128-B read requests are tallied as 64 B)'}
