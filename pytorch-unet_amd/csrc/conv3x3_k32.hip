@@ -39,6 +39,9 @@
 #ifndef UNETK_K32_STAMP
 #define UNETK_K32_STAMP 0    // diagnostic build: s_memtime stamps around the phases of conv3x3_k32n64_kernel
 #endif
+#ifndef UNETK_K32_DSTEPS
+#define UNETK_K32_DSTEPS 0   /* 0: 5 with resident weights (5 pieces), 3 otherwise (10 pieces) -- measured best of 3/5 */
+#endif
 #ifndef UNETK_K32_LDSSTATS
 #define UNETK_K32_LDSSTATS 0
 #endif
@@ -485,8 +488,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   // Every DMA piece of a stage goes out in its first DSTEPS k-steps and the pending stores in the steps after them:
   // the stores are then the YOUNGEST vector-memory operations of the stage and `s_waitcnt vmcnt(16)` at its end waits
   // for the DMA only -- the stores complete under the next stage instead of on the barrier.
-  constexpr int DSTEPS = 3;
-  constexpr int PPS = (NDMA + DSTEPS - 1) / DSTEPS;
+  // (stages without pending stores spread the pieces over all nine k-steps: an LDS-DMA instruction holds its wave for
+  // 60-185 cycles, and in a burst all eight phase-locked waves stall together while the matrix pipe drains)
+  constexpr int DSTEPS = UNETK_K32_DSTEPS ? UNETK_K32_DSTEPS : (WRES ? 5 : 3);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -539,10 +543,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     const char* src = (ok ? ximg : zero) + (ok ? dma_off[q] + (unsigned)in_chunk * 64u : 0u);
     glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
-  auto issue_weight = [&](int q, int chunk, unsigned buf, bool live) {
+  // branch-free: `live` is wave-uniform and a ?: over whole addresses becomes an s_cbranch, which ends the k-step's
+  // basic block (full lgkmcnt(0) wait, MFMA issue stalls) -- the base is selected by the caller once per stage and the
+  // lane offset is masked instead
+  auto issue_weight = [&](int q, const char* src_base, unsigned live_mask, unsigned buf) {
     const int fi = min(q * NW + wid, NFRAG - 1);
-    const char* src = live ? wbase + ((size_t)chunk * NFRAG + fi) * 1024 + lane * 16 : zero;
-    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    glds16_hidden(src_base + ((unsigned)(fi * 1024 + lane * 16) & live_mask), __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
 
   f32x4v acc[MB][2][NB16];
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
     for (int st = 0; st < 2; ++st)
       if (st < nst)
-        for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, st, ldsw0 + st * W_BYTES, true);
+        for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, wbase + (size_t)st * W_BYTES, ~0u, ldsw0 + st * W_BYTES);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   int curi = 0, curw = 0;
@@ -640,6 +646,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     }
     const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
     const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
+    const char* wsrc = live_w ? wbase + (size_t)next_wc * W_BYTES : zero;
+    const unsigned wmask = live_w ? ~0u : 0u;
     const int widx = WRES ? (ic & 1) : curw;
     int a_base = (int)(lds0 + curi * IN_BYTES) + (p00 << 6), w_base = (int)(ldsw0 + widx * W_BYTES) + lane * 16;
     asm volatile("" : "+v"(a_base), "+v"(w_base));           // keep tap / fragment offsets in the ds_read offset field
@@ -676,10 +684,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       // the LDS reads of the NEXT k-step first: they have this step's 16 MFMAs to land
       if (t + 1 < TAPS) load_ab(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+      constexpr int DS = FIRST ? DSTEPS : TAPS, PPS = (NDMA + DS - 1) / DS;
 #pragma unroll
       for (int q = t * PPS; q < (t + 1) * PPS && q < NDMA; ++q) {
         if (q < IN_PER_WAVE) issue_input(q, next_in, nbuf_in, live_in);
-        else issue_weight(q - IN_PER_WAVE, next_wc, nbuf_w, live_w);
+        else issue_weight(q - IN_PER_WAVE, wsrc, wmask, nbuf_w);
       }
       if (t + 2 < TAPS) a_addrs(t + 2);
       if constexpr (FIRST && STATS) {
@@ -687,8 +696,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       }
       if constexpr (FIRST) {
         // 16 stores of the previous tile: 3, 3, 3, 3, 2, 2 over the k-steps behind the DMA
-        constexpr int k0 = t < DSTEPS ? 16 : (t - DSTEPS) * 3 - (t - DSTEPS > 4 ? t - DSTEPS - 4 : 0);
-        constexpr int k1 = t < DSTEPS ? 16 : (t + 1 - DSTEPS) * 3 - (t + 1 - DSTEPS > 4 ? t + 1 - DSTEPS - 4 : 0);
+        constexpr int SS = TAPS - DSTEPS;                    // steps that carry stores
+        constexpr int k0 = t < DSTEPS ? 16 : (16 * (t - DSTEPS)) / SS;
+        constexpr int k1 = t < DSTEPS ? 16 : (16 * (t + 1 - DSTEPS)) / SS;
 #pragma unroll
         for (int k = k0; k < k1 && k < 16; ++k) emit_store(k);
       }
