@@ -292,7 +292,7 @@ def main(argv=None):
             torch.cuda.synchronize()
         table = kt.summary()
         n_l, ms, fl = 0, 0.0, 0.0
-        names = ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums', 'unetk_conv3x3_dgrad_bnsums',
+        names = ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums', 'unetk_conv3x3_dgrad_bn_reduce',
                  'unetk_conv3x3_fprop_bn_relu')
         for name in names:
             if name in table:

@@ -132,6 +132,17 @@ int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int p
  * slice, `scratch` c_up doubles) and writes db [c_up]. */
 int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,
                              double* sums, int n, int h, int w, int c_in, int c_out, int dtype, void* stream);
+/* dgrad of a DoubleConv's SECOND convolution fused with the first pass of the BatchNorm backward of its FIRST layer
+ * (unet_parts.py:15-21: conv -> BN -> ReLU -> conv -> ...; autograd runs ConvolutionBackward, ThresholdBackward and the
+ * reduction half of NativeBatchNormBackward as separate passes): besides dx it accumulates, from the value it stores
+ * and one read of that layer's pre-BN tensor `z_prev` [N][H][W][c_in] (pitch ldz), the two per-channel sums that
+ * unetk_bn_relu_bwd_reduce would form from dx and z_prev -- `sums` [UNETK_STAT_REPLICAS][c_in][2] doubles zeroed by the
+ * caller; scale/shift/mean/invstd: that layer's BatchNorm state [c_in].  Shapes whose kernel has no such epilogue run
+ * dgrad followed by unetk_bn_relu_bwd_reduce; the result is the same either way. */
+int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
+                                  int dx_choff, const void* z_prev, int ldz, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,
+                                  int c_out, int dtype, void* stream);
 int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_off, const void* dup, int ld, int n,
                                        int hs, int ws, int c_up, int pad_t, int pad_l, int h_up, int w_up,
                                        double* scratch, float* db, int dtype, void* stream);

@@ -473,8 +473,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
 //     registers, i.e. spills, and 11 % more matrix-pipe time at K = 576);
 //   * the 16 stores of tile i are issued two per k-step under the MFMAs of tile i+1's first stage (EXEC-masked inline
 //     asm: no branch splits the MFMA block), 8 bytes per lane, nontemporal.
-template <bool WRES, bool STATS>
+//
+// EPI: 0 plain store; 1 BatchNorm statistics of the output (forward); 2 (dgrad) the BN-backward sums of the layer that
+// produced this tensor (ConvParams::bn_z): that layer's z at the tile's pixels is fetched during the tile's LAST stage
+// -- into the registers the packed previous tile occupied until its stores went out in the first stage -- and the
+// masked sums are formed at the hand-over from the rounded values.
+template <bool WRES, int EPI>
 __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
+  constexpr bool STATS = EPI == 1, BNR = EPI == 2;
   constexpr int NB16 = 4, NW = 8, MB = 2, TR = MB * NW, HP = 34, NP = 4, TAPS = 9;
   constexpr int NPIX = (TR + 2) * HP;
   constexpr int IN_INSTR = (NPIX * NP + 63) / 64;            // 39 one-KiB DMA pieces
@@ -626,11 +632,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   int curi = 0, curw = 0;
 
+  // BNR: z of the producer layer for the tile in flight, [row][pixel set][pixel] x 4 adjacent channels (packed), and
+  // that layer's per-channel coefficients (re-fetched with every tile: they are not worth 12 registers for a whole launch)
+  unsigned zr[BNR ? MB : 1][2][4][2];
+  float* bn_coef = reinterpret_cast<float*>(smem + 2 * IN_BYTES + 2 * W_BYTES);   // [3][64]: scale, shift, mean
+  if constexpr (BNR) {
+    if (tid < 3 * BN) bn_coef[tid] = (tid < BN ? P.bn_scale : tid < 2 * BN ? P.bn_shift - BN : P.bn_mean - 2 * BN)[tid];
+  }
+  auto fetch_z = [&](int tile) {
+    const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
+    const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
+    const char* zimg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.bn_z) + (size_t)img * P.H * P.W * P.ld_bnz);
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int yc = min(y0 + MB * wid + mb, P.H - 1);        // clamped into the image: branch-free, masked at use
+      const char* zrow = zimg + (size_t)(yc * P.W) * P.ld_bnz * 2;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int xc = min(x0 + xg + 4 * ps + i, P.W - 1);
+          const u32x2 r = __builtin_nontemporal_load(
+              reinterpret_cast<const u32x2*>(zrow + (unsigned)(xc * P.ld_bnz + NB16 * c16) * 2u));
+          zr[mb][ps][i][0] = r[0];
+          zr[mb][ps][i][1] = r[1];
+        }
+    }
+  };
+
   unsigned long long ph[5] = {0, 0, 0, 0, 0};                // stamps: prologue reads, MFMA steps, wait, barrier, hand-over
-  auto run_stage = [&](auto first_c, int tile, int ic) {
+  auto run_stage = [&](auto first_c, auto fetch_c, int tile, int ic) {
     constexpr bool FIRST = decltype(first_c)::value;         // first chunk of a tile: C = 0, and the pending stores
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (UNETK_K32_STAMP) t0 = __builtin_amdgcn_s_memtime();
+    // BNR: the tile's last stage (never the first: the host sends Cin < 64 elsewhere) starts with the z fetch, which
+    // lands under its MFMAs (vmcnt(0) at its end).  A stage of its own in the code -- not a run-time test -- so that the
+    // z registers are defined on every path to the hand-over and dead before it.
+    if constexpr (decltype(fetch_c)::value && !(UNETK_K32_ABL & 16)) fetch_z(tile);
     int next_in = ic + 1;
     bool live_in = !(UNETK_K32_ABL & 4);
     if (ic + 1 == nin) {
@@ -732,8 +771,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   };
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
-    run_stage(std::true_type{}, tile, 0);
-    for (int ic = 1; ic < nin; ++ic) run_stage(std::false_type{}, tile, ic);
+    run_stage(std::true_type{}, std::false_type{}, tile, 0);
+    if constexpr (BNR) {
+      for (int ic = 1; ic + 1 < nin; ++ic) run_stage(std::false_type{}, std::false_type{}, tile, ic);
+      run_stage(std::false_type{}, std::true_type{}, tile, nin - 1);
+    } else {
+      for (int ic = 1; ic < nin; ++ic) run_stage(std::false_type{}, std::false_type{}, tile, ic);
+    }
 
     // ---- hand the tile over: round, statistics, remember where it goes.  Its stores ride under the next tile.
     unsigned long long th = 0;
@@ -753,7 +797,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps)
+      for (int ps = 0; ps < 2; ++ps) {
+        unsigned rnd[NB16][2];
 #pragma unroll
         for (int cb = 0; cb < NB16; ++cb) {
           f32x4v a = acc[mb][ps][cb];
@@ -762,9 +807,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
             for (int i = 0; i < 4; ++i) a[i] = (st_xl + 4 * ps + i < st_wlim[mb]) ? a[i] : 0.f;
           }
           bf16x2 lo = {(bf16)a[0], (bf16)a[1]}, hi = {(bf16)a[2], (bf16)a[3]};
-          pk[mb][ps][cb][0] = __builtin_bit_cast(unsigned, lo);
-          pk[mb][ps][cb][1] = __builtin_bit_cast(unsigned, hi);
+          rnd[cb][0] = __builtin_bit_cast(unsigned, lo);
+          rnd[cb][1] = __builtin_bit_cast(unsigned, hi);
         }
+        if constexpr (BNR && !(UNETK_K32_ABL & 8)) {
+          float bsc[NB16], bsh[NB16], bmu[NB16];              // read per group: 12 registers only while they are used
+#pragma unroll
+          for (int cb = 0; cb < NB16; ++cb) {
+            bsc[cb] = bn_coef[NB16 * c16 + cb]; bsh[cb] = bn_coef[BN + NB16 * c16 + cb]; bmu[cb] = bn_coef[2 * BN + NB16 * c16 + cb];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            // (fence: the scheduler otherwise unpacks all 64 values of the tile up front and the allocator spills --
+            // scratch reloads with vmcnt(0) waits, which also wait for the next stage's DMA)
+            __builtin_amdgcn_sched_barrier(0);
+            const bool inside = st_xl + 4 * ps + i < st_wlim[mb];
+#pragma unroll
+            for (int cb = 0; cb < NB16; ++cb) {
+              const unsigned zw = zr[mb][ps][i][cb >> 1], dw = rnd[cb][i >> 1];
+              const float z = __uint_as_float((cb & 1) ? (zw & 0xffff0000u) : (zw << 16));
+              const float f = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
+              const float dz = (inside && fmaf(z, bsc[cb], bsh[cb]) > 0.f) ? f : 0.f;
+              tsum[cb] += dz;
+              tsq[cb] = fmaf(dz, z - bmu[cb], tsq[cb]);
+            }
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NB16; ++cb) { pk[mb][ps][cb][0] = rnd[cb][0]; pk[mb][ps][cb][1] = rnd[cb][1]; }
+      }
     if (UNETK_K32_STAMP) {
       asm volatile("" ::"v"(pk[1][1][NB16 - 1][1]));
       ph[4] += __builtin_amdgcn_s_memtime() - th;
@@ -784,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) emit_store(k);
 
-  if (STATS && P.stats != nullptr) {
+  if (EPI != 0 && P.stats != nullptr) {
 #pragma unroll
     for (int cb = 0; cb < NB16; ++cb) {                     // lanes l, l^16, l^32, l^48 hold the same channels
       tsum[cb] += __shfl_xor(tsum[cb], 16, 64);
@@ -805,15 +876,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       float v = 0;
 #pragma unroll
       for (int w8 = 0; w8 < NW; ++w8) v += part[w8 * 2 * BN + tid];
+      if constexpr (BNR) {
+        if (tid & 1) v *= P.bn_invstd[tid >> 1];              // sum dz (z - mean)  ->  sum dz xhat
+      }
       double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout) * 2 + tid;
       unsafeAtomicAdd(dst, (double)v);
     }
   }
 }
 
-template <bool WRES, bool STATS> int launch_k32n64(const ConvParams& P, hipStream_t s) {
-  constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024);
-  UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<WRES, STATS>), lds);
+template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024) + (EPI == 2 ? 1024 : 0);
+  UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<WRES, EPI>), lds);
   ConvParams Q = P;
   Q.tiles_x = host_cdiv(P.W, 32);
   Q.tiles_y = host_cdiv(P.H, 16);
@@ -838,7 +912,7 @@ template <bool WRES, bool STATS> int launch_k32n64(const ConvParams& P, hipStrea
     const char* e = getenv("UNETK_STAMP_PTR");
     Q.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
   }
-  hipLaunchKernelGGL((conv3x3_k32n64_kernel<WRES, STATS>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
+  hipLaunchKernelGGL((conv3x3_k32n64_kernel<WRES, EPI>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -883,13 +957,22 @@ int unetk_internal_conv3x3_k32(const void* params, void* stream) {
   if (P.Cin % 32 != 0 || P.Cout % 64 != 0) return UNETK_ERR_SHAPE;
   const int nb16 = conv3_k32_nb16(P.Cout);
   const bool aff = P.aff_scale != nullptr;
-  if (nb16 == 8) return aff ? launch_k32<8, true, false>(P, s) : launch_k32<8, false, false>(P, s);
+  const bool bnr = P.bn_z != nullptr;
+  if (nb16 == 8) {
+    if (bnr) return UNETK_ERR_UNFUSED;
+    return aff ? launch_k32<8, true, false>(P, s) : launch_k32<8, false, false>(P, s);
+  }
   const bool wres = P.Cin <= 64;                            // <= 2 weight stages: resident in the two buffers
   static const int nopipe = getenv("UNETK_K32_NOPIPE") ? atoi(getenv("UNETK_K32_NOPIPE")) : 0;
   if (!aff && P.Cout == 64 && !nopipe) {
-    if (P.stats != nullptr) return wres ? launch_k32n64<true, true>(P, s) : launch_k32n64<false, true>(P, s);
-    return wres ? launch_k32n64<true, false>(P, s) : launch_k32n64<false, false>(P, s);
+    if (bnr) {                                              // the z fetch needs a stage of its own behind the first
+      if (P.Cin < 64) return UNETK_ERR_UNFUSED;
+      return wres ? launch_k32n64<true, 2>(P, s) : launch_k32n64<false, 2>(P, s);
+    }
+    if (P.stats != nullptr) return wres ? launch_k32n64<true, 1>(P, s) : launch_k32n64<false, 1>(P, s);
+    return wres ? launch_k32n64<true, 0>(P, s) : launch_k32n64<false, 0>(P, s);
   }
+  if (bnr) return UNETK_ERR_UNFUSED;
   if (aff) return wres ? launch_k32<4, true, true>(P, s) : launch_k32<4, true, false>(P, s);
   return wres ? launch_k32<4, false, true>(P, s) : launch_k32<4, false, false>(P, s);
 }

@@ -2,6 +2,10 @@
 #pragma once
 #include "common.h"
 
+// internal (never crosses the C ABI): the kernel serving this shape has no fused epilogue of the kind asked for;
+// the caller runs the unfused sequence instead
+#define UNETK_ERR_UNFUSED (-1000)
+
 namespace {
 
 struct ConvParams {
@@ -14,6 +18,16 @@ struct ConvParams {
   void* pool;                // AFF only: MaxPool2d(2) of the stored activation [N][H/2][W/2][Cout] with pitch ldp, or NULL
   int ldp;
   double* stats;
+  // BN-backward reduction of the layer that PRODUCED this convolution's output tensor, folded into a dgrad epilogue
+  // (bn_z != NULL): with z that layer's pre-BatchNorm tensor [N][H][W][Cout] (pitch ld_bnz) and dx the value stored,
+  //   stats[.][c][0] += sum dx * [scale*z + shift > 0],   stats[.][c][1] += sum dx * [..] * (z - mean) * invstd
+  // -- the two sums unetk_bn_relu_bwd_reduce forms from a second pass over dx and z (elementwise.hip)
+  const void* bn_z;
+  int ld_bnz;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
   int N, H, W;       // tile grid domain (CONV3: image; PWT/CTD: the low-res grid)
   int Cin, Cout;     // GEMM K channels per tap, GEMM N channels
   int ldx, ldy, xoff, yoff;

@@ -963,6 +963,10 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     // 128-channel tiles: 64-byte input rows (KI = 2) refilled every second weight chunk; 64-channel tiles: 16 x 32
     // pixels, 32-channel chunks (measured slower and removed: 32-byte rows for the wide tiles -7 %, 32 x 32-pixel
     // tiles with four row blocks per wave -6 %, two 4-wave workgroups per CU -10 %)
+    // the BN-backward reduction of the producer layer is folded only into the pipelined 64-channel kernel above: here
+    // the epilogue is not overlapped with MFMA work, the extra read of z is exposed latency, and a fused version ran
+    // exactly as long as dgrad followed by the stand-alone pass (measured at 128..1024 channels)
+    if (P.bn_z != nullptr) return UNETK_ERR_UNFUSED;
     if (cfg.NB == 4)
       return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
     return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
@@ -995,15 +999,30 @@ int check_common(const void* x, int ldx, int xoff, const void* y, int ldy, int y
   return UNETK_OK;
 }
 
+struct BnReduceArgs {       // ConvParams::bn_z and friends
+  const void* z;
+  int ldz;
+  const float *scale, *shift, *mean, *invstd;
+};
+
 int conv3x3_common(const void* x, int ldx, int xoff, const void* wpk, void* y, int ldy, int yoff, double* stats,
                    int n, int h, int w, int cin, int cout, int dtype, void* stream, const float* aff_scale = nullptr,
-                   const float* aff_shift = nullptr, void* pool = nullptr, int ldp = 0) {
+                   const float* aff_shift = nullptr, void* pool = nullptr, int ldp = 0,
+                   const BnReduceArgs* bnr = nullptr) {
   if (n <= 0 || h <= 0 || w <= 0 || !x || !wpk || !y) return UNETK_ERR_ARG;
   if (int e = check_common(x, ldx, xoff, y, ldy, yoff, cin, cout, dtype, 64)) return e;
   if ((long)h * w * (ldx > ldy ? ldx : ldy) >= 0x7fffffffL) return UNETK_ERR_SHAPE;   // int32 in-image offsets
   ConvParams P{};
   P.x = x; P.wpk = wpk; P.y = y; P.stats = stats; P.aff_scale = aff_scale; P.aff_shift = aff_shift;
   P.pool = pool; P.ldp = ldp;
+  if (bnr != nullptr) {
+    const int es = dtype == UNETK_BF16 ? 2 : 4;
+    if (!bnr->z || !bnr->scale || !bnr->shift || !bnr->mean || !bnr->invstd || !stats) return UNETK_ERR_ARG;
+    if (bnr->ldz < cout || (long)h * w * bnr->ldz >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+    if (!aligned16(bnr->z) || (bnr->ldz * es) % 16) return UNETK_ERR_ALIGN;
+    P.bn_z = bnr->z; P.ld_bnz = bnr->ldz;
+    P.bn_scale = bnr->scale; P.bn_shift = bnr->shift; P.bn_mean = bnr->mean; P.bn_invstd = bnr->invstd;
+  }
   P.N = n; P.H = h; P.W = w; P.Cin = cin; P.Cout = cout;
   P.ldx = ldx; P.ldy = ldy; P.xoff = xoff; P.yoff = yoff;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = cout / 64;
@@ -1041,6 +1060,22 @@ int unetk_conv3x3_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk,
 int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int dx_choff,
                              double* sums, int n, int h, int w, int c_in, int c_out, int dtype, void* stream) {
   return conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, sums, n, h, w, c_out, c_in, dtype, stream);
+}
+
+int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
+                                  int dx_choff, const void* z_prev, int ldz, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,
+                                  int c_out, int dtype, void* stream) {
+  const BnReduceArgs bnr{z_prev, ldz, scale, shift, mean, invstd};
+  const int e = conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, sums, n, h, w, c_out, c_in, dtype, stream,
+                               nullptr, nullptr, nullptr, 0, &bnr);
+  if (e != UNETK_ERR_UNFUSED) return e;
+  // the kernel serving this shape has no such epilogue: plain dgrad, then the stand-alone reduction pass
+  if (int e2 = conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, nullptr, n, h, w, c_out, c_in, dtype, stream))
+    return e2;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  return unetk_bn_relu_bwd_reduce(static_cast<const char*>(dx) + (size_t)dx_choff * es, lddx, z_prev, ldz, scale, shift,
+                                  mean, invstd, sums, (int64_t)n * h * w, c_in, dtype, stream);
 }
 
 int unetk_convT2x2_fwd(const void* x, int ldx, const void* wpk, const float* bias, void* y, int ldy, int y_choff,

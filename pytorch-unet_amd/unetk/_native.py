@@ -109,6 +109,8 @@ class KernelTimer:
             return 2.0 * a[11] * a[12] * a[13] * 9 * a[14] * a[15]
         if name == 'unetk_conv3x3_dgrad':
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
+        if name == 'unetk_conv3x3_dgrad_bn_reduce':
+            return 2.0 * a[14] * a[15] * a[16] * 9 * a[17] * a[18]
         if name == 'unetk_conv3x3_wgrad':
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
         if name == 'unetk_conv3x3_first_fprop':

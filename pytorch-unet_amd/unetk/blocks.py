@@ -10,6 +10,8 @@ Reference semantics restated (file:line into the reference):
   up_*            unet/unet_parts.py:49-67   Upsample|ConvTranspose2d -> F.pad -> cat([skip, up])
   head_*          unet/unet_parts.py:74      Conv2d k=1 + bias
 """
+import os
+
 import torch
 
 from . import ops
@@ -185,18 +187,25 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     return act, (x, y, st)
 
 
-def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
+# fold the first layer's BN-backward reduction into the second layer's dgrad epilogue (UNETK_FUSE_BN_REDUCE=0: A/B runs)
+FUSE_BN_REDUCE = os.environ.get('UNETK_FUSE_BN_REDUCE', '1') != '0'
+
+
+def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None,
+                     bn_sums=None, bn_prev=None):
     """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing).
     dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient).
     dhead: (dlogits, OutConv weight) when OutConv consumed this layer's output (`dact` is then None).
-    dx_sums: zeroed [REPLICAS, c_in, 2] accumulator for the per-channel sums of the input gradient."""
+    dx_sums: zeroed [REPLICAS, c_in, 2] accumulator for the per-channel sums of the input gradient.
+    bn_sums: this layer's BN-backward sums, already formed by the dgrad that wrote `dact`.
+    bn_prev: (z, BNState) of the layer that produced this layer's input: returns (dx, that layer's bn_sums)."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
     if not _bn_uses_batch_stats(bn):
         raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference trains in train mode)')
     dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
     dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
-    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead)
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead, sums=bn_sums)
     dw = _grad_buf(grads, conv.weight)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)
@@ -206,7 +215,8 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
     ops.conv3x3_wgrad(x, dy, dw)
     if not need_dx:
         return None
-    return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums)
+    return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums,
+                             bn_prev=bn_prev)
 
 
 def _grad_buf(grads, p):
@@ -230,8 +240,13 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
 def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
     seq = dc.double_conv
     s1, s2 = saved
-    da1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead)
-    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums)
+    if FUSE_BN_REDUCE:
+        # s1 = (x, z1, state1): the second conv consumed relu(bn(z1)), so its dgrad epilogue can reduce for BN 1
+        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead,
+                                      bn_prev=(s1[1], s1[2]))
+    else:
+        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead), None
+    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums, bn_sums=sums1)
 
 
 def double_conv_params(dc):

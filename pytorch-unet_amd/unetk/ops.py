@@ -148,10 +148,35 @@ def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None, pool_out=None):
     return out
 
 
-def conv3x3_dgrad(dy, wpk_d, c_in, out=None, sums=None):
+def conv3x3_dgrad(dy, wpk_d, c_in, out=None, sums=None, bn_prev=None):
     """sums: optional zeroed fp64 [REPLICAS, c_in, 2] that receives the per-channel sums of the written gradient
-    (the conv epilogue's fused statistics; used for the ConvTranspose2d bias gradient)."""
+    (the conv epilogue's fused statistics; used for the ConvTranspose2d bias gradient).
+    bn_prev: (z, BNState) of the conv -> BN -> ReLU layer whose activation this convolution consumed: the epilogue
+    also forms that layer's BN-backward sums (what unetk_bn_relu_bwd_reduce would compute from the returned gradient);
+    returns (dx, bn_sums) then -- pass bn_sums to bn_relu_bwd(sums=...)."""
     require_cuda(dy, wpk_d)
+    if bn_prev is not None:
+        if sums is not None:
+            raise RuntimeError('conv3x3 dgrad: channel sums and BN-backward sums cannot be fused into one launch')
+        z, st = bn_prev
+        n, h, w, c_out, lddy = nhwc_meta(dy, 'conv3x3 dgrad input')
+        zn, zh, zw, zc, ldz = nhwc_meta(z, 'producer layer pre-BN tensor')
+        if (zn, zh, zw, zc) != (n, h, w, c_in) or z.dtype != dy.dtype:
+            raise RuntimeError('conv3x3 dgrad: producer layer tensor does not match the input gradient')
+        if out is None:
+            out = new_nhwc(n, h, w, c_in, dy.dtype, dy.device)
+        on, oh, ow, oc, lddx = nhwc_meta(out, 'conv3x3 dgrad output')
+        if (on, oh, ow, oc) != (n, h, w, c_in) or out.dtype != dy.dtype or wpk_d.dtype != dy.dtype:
+            raise RuntimeError('conv3x3 dgrad: output/weight do not match the input')
+        if wpk_d.numel() != 9 * c_in * c_out:
+            raise RuntimeError('conv3x3 dgrad: packed weight has the wrong size')
+        bn_sums = new_stats(c_in, dy.device)
+        check(fn['unetk_conv3x3_dgrad_bn_reduce'](dy.data_ptr(), lddy, 0, wpk_d.data_ptr(), out.data_ptr(), lddx, 0,
+                                                  z.data_ptr(), ldz, st.scale.data_ptr(), st.shift.data_ptr(),
+                                                  st.mean.data_ptr(), st.invstd.data_ptr(), bn_sums.data_ptr(), n, h, w,
+                                                  c_in, c_out, dtype_code(dy.dtype), stream_ptr()),
+              'unetk_conv3x3_dgrad_bn_reduce')
+        return out, bn_sums
     n, h, w, c_out, lddy = nhwc_meta(dy, 'conv3x3 dgrad input')
     if out is None:
         out = new_nhwc(n, h, w, c_in, dy.dtype, dy.device)
@@ -391,25 +416,35 @@ def head_bwd_fusable(c, n_classes, dtype):
     return n_classes <= 4 and pool_bwd_fusable(c, dtype)
 
 
-def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None):
+def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None, sums=None):
     """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
     dpool: the layer's output also fed MaxPool2d(2) -- `dout` is then only the skip-connection gradient and the
     pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass).
     dhead: (dlogits [N,H,W,n_classes], OutConv weight fp32 [n_classes, C], dw, db) -- the layer's output fed OutConv;
     `dout` is None and the 1x1 convolution's input gradient is formed on the fly; dw/db (fp32 gradient buffers of
-    OutConv's weight [n_classes,C,1,1] and bias, or None) are filled as a by-product of the reduction pass."""
+    OutConv's weight [n_classes,C,1,1] and bias, or None) are filled as a by-product of the reduction pass.
+    sums: the reduction pass's result when the dgrad that wrote `dout` already formed it (conv3x3_dgrad(bn_prev=...))."""
+    if sums is not None and (dpool is not None or dhead is not None):
+        raise RuntimeError('bn_relu_bwd: precomputed sums only apply to the plain (no pool, no head) layer')
     if dhead is not None:
         return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out, *dhead[2:])
     n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
     _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
     dc = dtype_code(y.dtype)
     npix = n * h * w
-    sums = new_stats(c, y.device)
+    have_sums = sums is not None
+    if have_sums:
+        if sums.dtype != torch.float64 or sums.numel() != nat.STAT_REPLICAS * c * 2:
+            raise RuntimeError('bn_relu_bwd: sums must be float64 [REPLICAS, C, 2]')
+    else:
+        sums = new_stats(c, y.device)
     coef = torch.empty((3, c), dtype=torch.float32, device=y.device)
     if out is None:
         out = new_nhwc(n, h, w, c, y.dtype, y.device)
     _, _, _, _, ldo = nhwc_meta(out, 'bn grad output')
-    if dpool is not None:
+    if have_sums:
+        pass
+    elif dpool is not None:
         pn, ph, pw, pc, lddp = nhwc_meta(dpool, 'pool grad')
         if (pn, ph, pw, pc) != (n, h // 2, w // 2, c) or dpool.dtype != y.dtype or dout.dtype != y.dtype:
             raise RuntimeError('bn_relu_bwd: dpool must be [N, H//2, W//2, C] of the activation dtype')

@@ -84,3 +84,85 @@ def test_conv3x3_rejects_bad_shapes():
         ops.conv3x3_fprop(x, torch.zeros(9 * 48 * 64, dtype=torch.bfloat16, device='cuda'), 64)
     with pytest.raises(RuntimeError):
         ops.conv3x3_fprop(torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16), torch.zeros(9 * 64 * 64, dtype=torch.bfloat16), 64)
+
+
+class _State:
+    """The four BatchNorm rows the backward kernels read (ops.BNState without the module plumbing)."""
+
+    def __init__(self, c, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.mean = (torch.rand(c, generator=g) - 0.5).cuda()
+        self.invstd = (0.5 + torch.rand(c, generator=g)).cuda()
+        gamma = (0.5 + torch.rand(c, generator=g)) * torch.where(torch.rand(c, generator=g) < 0.2, -1.0, 1.0)
+        beta = (torch.rand(c, generator=g) - 0.5) * 0.5
+        self.scale = (gamma.cuda() * self.invstd)
+        self.shift = (beta.cuda() - self.mean * self.scale)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,h,w,cin,cout', [
+    (1, 16, 32, 64, 64),        # one tile of the 64-channel kernel (bf16: the pipelined k32 kernel, weights resident)
+    (2, 37, 75, 64, 64),        # ragged both ways, several tiles per workgroup
+    (1, 21, 45, 128, 128),      # the 128-channel n-tile kernel
+    (2, 9, 33, 256, 128),       # GEMM-N = 256: two n-tiles, GEMM-K = 128
+    (1, 19, 50, 64, 128),       # GEMM-N = 64, GEMM-K = 128: weights streamed (not the UNet's case, but the kernel's)
+    (1, 5, 3, 64, 64),          # image smaller than a tile
+])
+def test_conv3x3_dgrad_with_bn_reduce_of_the_producer_layer(dtype, n, h, w, cin, cout):
+    """unetk_conv3x3_dgrad_bn_reduce == unetk_conv3x3_dgrad followed by unetk_bn_relu_bwd_reduce: the gradient
+    bit for bit, the two per-channel sums to fp32 summation-order accuracy."""
+    from unetk import ops
+    from unetk._native import fn, check, dtype_code, stream_ptr
+    dy = _rand((n, h, w, cout), 11).to(dtype).cuda()
+    wq = _rand((cout, cin, 3, 3), 12, 0.05).to(dtype).float()
+    wpk = ops.pack_weight(1, wq.cuda(), cout, cin, dtype)
+    z = _rand((n, h, w, cin), 13, 2.0).to(dtype).cuda()
+    st = _State(cin, 14)
+    ref_dx = ops.conv3x3_dgrad(dy, wpk, cin)
+    ref_sums = ops.new_stats(cin, 'cuda')
+    check(fn['unetk_bn_relu_bwd_reduce'](ref_dx.data_ptr(), cin, z.data_ptr(), cin, st.scale.data_ptr(),
+                                         st.shift.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(),
+                                         ref_sums.data_ptr(), n * h * w, cin, dtype_code(dtype), stream_ptr()), 'reduce')
+    dx, sums = ops.conv3x3_dgrad(dy, wpk, cin, bn_prev=(z, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, ref_dx)
+    a, b = sums.sum(0).cpu().numpy(), ref_sums.sum(0).cpu().numpy()
+    # scale of a channel's sums: sum |dz|, sum |dz xhat| -- cancellation must not hide an error
+    d = ref_dx.double().reshape(-1, cin)
+    zz = z.double().reshape(-1, cin)
+    m = (zz * st.scale.double() + st.shift.double() > 0)
+    mag1 = (d.abs() * m).sum(0).cpu().numpy()
+    mag2 = ((d * (zz - st.mean.double()) * st.invstd.double()).abs() * m).sum(0).cpu().numpy()
+    assert np.all(np.abs(a[:, 0] - b[:, 0]) <= 2e-5 * mag1 + 1e-6)
+    assert np.all(np.abs(a[:, 1] - b[:, 1]) <= 2e-5 * mag2 + 1e-6)
+    assert mag1.min() > 0 and np.abs(b).max() > 0
+    # ... and the masked sums themselves against fp64 (the stand-alone pass has its own tests; this pins the fused one)
+    e1 = (d * m).sum(0).cpu().numpy()
+    e2 = (d * m * (zz - st.mean.double()) * st.invstd.double()).sum(0).cpu().numpy()
+    assert np.all(np.abs(a[:, 0] - e1) <= 2e-5 * mag1 + 1e-6)
+    assert np.all(np.abs(a[:, 1] - e2) <= 2e-5 * mag2 + 1e-6)
+
+
+def test_double_conv_backward_same_with_and_without_fused_bn_reduce():
+    """blocks.double_conv_bwd with FUSE_BN_REDUCE on/off: identical input gradient, BN/conv gradients to summation order."""
+    from unetk import blocks
+    from unet.unet_parts import DoubleConv
+    torch.manual_seed(3)
+    dc = DoubleConv(64, 128).cuda().train()
+    x = _rand((2, 26, 37, 64), 21).to(torch.bfloat16).cuda()
+    da = _rand((2, 26, 37, 128), 22).to(torch.bfloat16).cuda()
+    outs = []
+    for fuse in (False, True):
+        blocks.FUSE_BN_REDUCE = fuse
+        try:
+            a2, saved = blocks.double_conv_fwd(dc, x, torch.bfloat16)
+            grads = {}
+            dx = blocks.double_conv_bwd(dc, saved, da, grads, True)
+            torch.cuda.synchronize()
+            outs.append((dx.clone(), {k: v.clone() for k, v in grads.items()}))
+        finally:
+            blocks.FUSE_BN_REDUCE = True
+    (dx0, g0), (dx1, g1) = outs
+    assert float((dx0.float() - dx1.float()).abs().max()) <= 1e-2 * float(dx0.float().abs().max())
+    for p in g0:
+        assert float((g0[p] - g1[p]).abs().max()) <= 2e-3 * float(g0[p].abs().max()) + 1e-7
