@@ -566,6 +566,195 @@ int pick_nsplit3(int ntiles, int npairs) {
   return ns;
 }
 
+// ================================================================================================================
+// ConvTranspose2d k2 s2 wgrad, second generation (c_in % 128 == 0: every level of the UNet).
+//
+//   dw[ci][co][tap] = sum over low-res pixels p   dy[up(p, tap)][co] * x[p][ci]        (four independent GEMMs,
+//   rows = co, cols = ci, GEMM-K = pixels; both operands pixel-major -> transposed LDS reads as above)
+//
+// The first-generation kernel stages a tile, waits for it, computes, and stages the next (0.18 matrix-pipe busy).  Here
+//   tile     2 rows x 32 columns of low-res pixels (64 = four 16-pixel k-steps) x 64 co x 128 ci x 4 taps
+//   LDS      per buffer six [64 px][128 B] arrays -- x channels 0-63, x 64-127, dy tap 0..3 -- = 48 KiB, THREE buffers:
+//            the DMA of tile i+2 is issued while tile i is consumed (a 64-pixel tile is ~0.5 us of MFMA work, less than
+//            one HBM round trip, so one tile of look-ahead would leave every wave waiting on vmcnt)
+//   waves    8 = 4 taps x 2 k-groups: wave (tap, kg) takes k-steps 2kg, 2kg+1 of its tap: 2 dy fragments (co blocks) and
+//            4 x fragments (ci blocks) per k-step feed 8 MFMAs -- 0.75 KiB of LDS reads per MFMA (one block per wave
+//            and tap would need 1.25); the two k-groups are added through LDS at the end
+//   DMA      wave w owns pixels 8w..8w+7 of every array: six 1-KiB pieces per tile, lane offsets fixed for the launch
+//            (only the tile base and the ragged-edge mask change), one piece between MFMAs
+// Partial sums: slab[split][tap][co][ci], summed in fixed order by the reduce kernels below.
+struct WgradTParams {
+  const bf16* dy;     // up-sampled gradient (channel offset applied)
+  const bf16* x;      // low-res input
+  float* slab;
+  int N, H, W;        // low-res grid
+  int Co, Ci, lddy, ldx;
+  int Hs, Ws, padT, padL;
+  int tiles_x, tiles_y, ntiles, nsplit, row_tiles, col_tiles;
+};
+
+constexpr int WT_ARR = 64 * 128;          // one array
+constexpr int WT_BUF = 6 * WT_ARR;
+constexpr int WT_NBUF = 3;
+
+__global__ __launch_bounds__(512) void wgradT_bf16_kernel(WgradTParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tap = wid & 3, kg = wid >> 2;
+
+  const int npairs = P.row_tiles * P.col_tiles;
+  int lin = blockIdx.x;                           // XCD-major, see wgrad3
+  if ((gridDim.x & 7) == 0) lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int pair = lin % npairs, split = lin / npairs;
+  const int r0 = (pair / P.col_tiles) * 64, c0 = (pair % P.col_tiles) * 128;
+  const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
+  const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
+
+  // transposed-read addresses inside one array: [32-channel block][ds_read of the pair]; a k-step adds 16 pixel rows
+  const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+  int addr[2][2];
+#pragma unroll
+  for (int cblk = 0; cblk < 2; ++cblk)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int pb = 8 * (g >> 1) + 4 * rd + q4;
+      const int piece = cblk * 4 + 2 * (g & 1) + (pp >> 1);
+      addr[cblk][rd] = pb * 128 + ((piece ^ swz(pb)) << 4) + (pp & 1) * 8;
+    }
+
+  // DMA: this lane's 16 bytes of the wave's pixel rows, relative to the tile's first pixel
+  const int dp = 8 * wid + (lane >> 3);                       // pixel of the tile
+  const int dr = dp >> 5, dc = dp & 31;
+  const int dpiece = (lane & 7) ^ swz(dp);
+  const unsigned offx = ((unsigned)(dr * P.W + dc) * (unsigned)P.ldx + dpiece * 8u) * 2u;
+  const unsigned offd = ((unsigned)(2 * dr * P.Ws + 2 * dc) * (unsigned)P.lddy + dpiece * 8u) * 2u;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const unsigned lds0 = lds_address(smem);
+  const int tiles_per_img = P.tiles_x * P.tiles_y;
+  const char* sx = nullptr;
+  const char* sd = nullptr;
+  bool sok = false;
+  // the tile being staged, advanced incrementally (a tile is 16 MFMAs per wave: two integer divisions per tile were
+  // most of the 126 scalar instructions the first version spent per tile)
+  int s_img, s_ty, s_tx;
+  {
+    const int first = min(t_begin, P.ntiles - 1);
+    s_img = first / tiles_per_img;
+    const int rem = first - s_img * tiles_per_img;
+    s_ty = rem / P.tiles_x;
+    s_tx = rem - s_ty * P.tiles_x;
+  }
+  auto stage_tile = [&](bool live) {                          // stages (s_img, s_ty, s_tx), then steps to the next tile
+    const int y0 = s_ty * 2, x0 = s_tx * 32;
+    sx = reinterpret_cast<const char*>(P.x + ((size_t)(s_img * P.H + y0) * P.W + x0) * P.ldx + c0);
+    sd = reinterpret_cast<const char*>(P.dy + ((size_t)(s_img * P.Hs + 2 * y0 + P.padT) * P.Ws + 2 * x0 + P.padL) * P.lddy + r0);
+    sok = live && (y0 + dr < P.H) && (x0 + dc < P.W);
+    if (live) {
+      if (++s_tx == P.tiles_x) {
+        s_tx = 0;
+        if (++s_ty == P.tiles_y) { s_ty = 0; ++s_img; }
+      }
+    }
+  };
+  auto issue_piece = [&](int q, unsigned buf) {               // branch-free; q: array
+    const char* src;
+    if (q < 2) src = sx + (offx + q * 128u);
+    else src = sd + (offd + (unsigned)(((q - 2) >> 1) * P.Ws + ((q - 2) & 1)) * (unsigned)P.lddy * 2u);
+    src = sok ? src : zero;
+    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + q * WT_ARR + wid * 1024));
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+  // Three tiles of look-ahead in three buffers: the fragments of tile i+1 are read into a second register set while the
+  // MFMAs of tile i run, so buffer i % 3 is free as soon as every wave has passed the barrier of iteration i and takes
+  // the DMA of tile i+3.  Every stage issues exactly six pieces per wave (zero page past the end), so `vmcnt(6)` always
+  // means "everything but the youngest stage has landed".
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    stage_tile(t_begin + k < t_end);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_piece(q, lds0 + k * WT_BUF);
+  }
+  bf16x8 fa[2][2][2], fb[2][2][4];                            // [register set][k-step][block]
+  auto read_frags = [&](int bufi, bf16x8 (&a)[2][2], bf16x8 (&b)[2][4]) {
+    const char* buf = smem + bufi * WT_BUF + (2 * kg) * 2048;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+        a[ks][rb] = tr_read8(buf + ks * 2048 + (2 + tap) * WT_ARR + addr[rb][0], buf + ks * 2048 + (2 + tap) * WT_ARR + addr[rb][1]);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        b[ks][cb] = tr_read8(buf + ks * 2048 + (cb >> 1) * WT_ARR + addr[cb & 1][0],
+                             buf + ks * 2048 + (cb >> 1) * WT_ARR + addr[cb & 1][1]);
+    }
+  };
+  asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+  read_frags(0, fa[0], fb[0]);
+  int cur = 0;                                                // buffer of the tile whose MFMAs run
+  auto run_tile = [&](auto set_c, int tile) {
+    constexpr int SET = decltype(set_c)::value;
+    // tile+1 landed (own pieces; the barrier makes that all waves'), own fragments of `tile` arrived, and every wave has
+    // finished reading buffer `cur`
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    read_frags(nxt, fa[SET ^ 1], fb[SET ^ 1]);
+    stage_tile(tile + 3 < t_end);
+    const unsigned nbuf = lds0 + cur * WT_BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        if (ks * 2 + rb < 3) {                                // six pieces over the tile's 16 MFMAs
+          issue_piece(2 * (ks * 2 + rb), nbuf);
+          issue_piece(2 * (ks * 2 + rb) + 1, nbuf);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = WG_MFMA(fa[SET][ks][rb], fb[SET][ks][cb], acc[rb][cb]);
+      }
+    cur = nxt;
+  };
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    run_tile(std::integral_constant<int, 0>{}, tile);
+    if (tile + 1 < t_end) run_tile(std::integral_constant<int, 1>{}, tile + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- k-group 1 hands its partial sums to k-group 0 through LDS (4 taps x 8 blocks x 16 x 64 floats = 128 KiB)
+  float* xch = reinterpret_cast<float*>(smem);
+  if (kg == 1) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xch[(((tap * 2 + rb) * 4 + cb) * 16 + i) * 64 + lane] = acc[rb][cb][i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (kg == 0) {
+    const int j = lane & 31, h = lane >> 5;
+    float* out = P.slab + ((size_t)split * 4 + tap) * P.Co * P.Ci;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = r0 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          out[(size_t)row * P.Ci + c0 + cb * 32 + j] =
+              acc[rb][cb][i] + xch[(((tap * 2 + rb) * 4 + cb) * 16 + i) * 64 + lane];
+        }
+  }
+}
+
 // out[col][row][tap] = sum_s slab[s][tap][row][col]   (out = PyTorch's [Co][Ci][3][3] resp. [Ci][Co][2][2]: s_col =
 // rows*taps, s_row = taps).  One workgroup = 32 cols x 8 rows x all taps, transposed through LDS: the slab is read in
 // 128-byte runs (32 cols), the parameter gradient written in runs of 8*taps floats.  Fixed summation order.
@@ -811,6 +1000,10 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
       if (s4 > slabs) slabs = s4;
     }
   }
+  if (kind == 1 && c_in % 128 == 0) {   // second-generation kernel: 2 x 32-pixel tiles, 64 x 128 channel pairs
+    const int64_t st = pick_nsplit3(n * host_cdiv(h, 2) * host_cdiv(w, 32), (c_in / 128) * (c_out / 64));
+    if (st > slabs) slabs = st;
+  }
   return slabs * taps * c_in * c_out * 4;
 }
 
@@ -905,6 +1098,26 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
     UNETK_CHECK_LAUNCH();
     const long totalq = 4L * c_in * c_out;
     launch_wgrad_reduce((const float*)workspace, dw, Q.nsplit, 4, c_out, c_in, accumulate, (hipStream_t)stream);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
+  static const int gen2 = getenv("UNETK_WGRADT_GEN2") ? atoi(getenv("UNETK_WGRADT_GEN2")) : 1;   // 0: A/B runs
+  if (c_in % 128 == 0 && gen2) {
+    if ((int64_t)hs * ws * lddy * 2 >= (int64_t)1 << 32 || (int64_t)h * w * ldx * 2 >= (int64_t)1 << 32)
+      return UNETK_ERR_SHAPE;                                  // 32-bit DMA offsets inside an image
+    WgradTParams T{};
+    T.dy = (const bf16*)dy + dy_choff; T.x = (const bf16*)x; T.slab = (float*)workspace;
+    T.N = n; T.H = h; T.W = w; T.Co = c_out; T.Ci = c_in; T.lddy = lddy; T.ldx = ldx;
+    T.Hs = hs; T.Ws = ws; T.padT = pad_t; T.padL = pad_l;
+    T.tiles_x = host_cdiv(w, 32); T.tiles_y = host_cdiv(h, 2); T.ntiles = n * T.tiles_x * T.tiles_y;
+    T.row_tiles = c_out / 64; T.col_tiles = c_in / 128;
+    T.nsplit = pick_nsplit3(T.ntiles, T.row_tiles * T.col_tiles);
+    const size_t ldst = (size_t)WT_NBUF * WT_BUF;
+    UNETK_ALLOW_LDS((wgradT_bf16_kernel), ldst);
+    hipLaunchKernelGGL(wgradT_bf16_kernel, dim3(T.row_tiles * T.col_tiles * T.nsplit), dim3(512), ldst,
+                       (hipStream_t)stream, T);
+    UNETK_CHECK_LAUNCH();
+    launch_wgrad_reduce((const float*)workspace, dw, T.nsplit, 4, c_out, c_in, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }

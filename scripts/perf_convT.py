@@ -8,6 +8,8 @@ N = 16
 # (low-res h, w, c_in, skip H, W)
 layers = [(40, 59, 1024, 80, 119), (80, 119, 512, 160, 239), (160, 239, 256, 320, 479), (320, 479, 128, 640, 959)]
 dt = torch.bfloat16
+if os.environ.get('ONLY'):
+    layers = [layers[int(i)] for i in os.environ['ONLY'].split(',')]
 
 
 def timeit(f, reps=20):

@@ -114,17 +114,22 @@ def test_convT_dgrad(dtype):
     assert rel_err(_np(dx), ref) < TOL[dtype]
 
 
-def test_convT_wgrad_bf16():
+@pytest.mark.parametrize('n,h,w,cin,co,hs,ws', [
+    (2, 8, 11, 128, 64, 17, 23),       # the pipelined kernel (c_in % 128 == 0): one 64 x 128 channel pair, ragged width
+    (1, 9, 70, 256, 128, 20, 143),     # odd low-res height, three column tiles, 2 x 2 channel pairs, F.pad offsets (1, 1)
+    (3, 5, 33, 128, 128, 10, 66),      # more tiles than a look-ahead of three, c_out = c_in
+    (2, 8, 11, 192, 64, 17, 23),       # c_in % 128 != 0: the first-generation kernel
+])
+def test_convT_wgrad_bf16(n, h, w, cin, co, hs, ws):
     from oracle import ops_numpy as O
     from unetk import ops
-    n, h, w, cin, hs, ws = 2, 8, 11, 128, 17, 23
-    co = cin // 2
     x = _rand((n, h, w, cin), 37).bfloat16()
-    dcat = _rand((n, hs, ws, cin), 38).bfloat16()
+    cs = 64                                                    # skip channels in front of the up-sampled half
+    dcat = _rand((n, hs, ws, cs + co), 38).bfloat16()
     dw = torch.empty((cin, co, 2, 2), device='cuda')
     db = torch.empty((co,), device='cuda')
-    ops.convT2x2_wgrad(x.cuda(), dcat.cuda(), co, dw, db, 0, 0)
-    _, dup = O.pad_cat_bwd((n, hs, ws, co), (n, 2 * h, 2 * w, co), _np(dcat))
+    ops.convT2x2_wgrad(x.cuda(), dcat.cuda(), cs, dw, db, (hs - 2 * h) // 2, (ws - 2 * w) // 2)
+    _, dup = O.pad_cat_bwd((n, hs, ws, cs), (n, 2 * h, 2 * w, co), _np(dcat))
     _, rw, rb = O.convT2x2_bwd(_np(x), np.zeros((cin, co, 2, 2)), dup)
     assert rel_err(_np(dw), rw) < 1e-4
     assert rel_err(_np(db), rb) < 1e-4
