@@ -13,6 +13,7 @@ import torch.distributed as dist
 
 class FlatGrads:
     def __init__(self, net, process_group=None, bucket_bytes=25 << 20, force_collectives=False):
+        self.module_order = [p for p in net.parameters()]     # torch.optim's order (checkpoints of a stock optimizer)
         self.params = list(reversed(net.hot_path_params()))   # approximate completion order; ranges are re-derived
         order = []
         for blk in self._completion_blocks(net):
@@ -36,6 +37,7 @@ class FlatGrads:
         self.views = {}
         self._pending = [0, 0]
         self._works = []
+        self._unconsumed = False      # a backward pass filled `flat` and no optimizer step / zero_grad has taken it yet
         net._grad_ready_hook = self.ready
         net._initial_grads = self.initial_grads
 
@@ -52,13 +54,23 @@ class FlatGrads:
 
     def initial_grads(self):
         """Fresh flat buffer + per-parameter views for one backward pass."""
+        if self._unconsumed:
+            # every backward pass WRITES a fresh flat buffer (the reference zeroes its gradients before each backward:
+            # train.py:113); a second backward would silently drop the first one's gradients instead of adding to them
+            raise RuntimeError('gradient accumulation is not supported on the flat gradient buffer: call '
+                               'optimizer.step() or optimizer.zero_grad() between backward passes')
         dev = self.params[0].device
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)   # zero: alignment gaps enter the norm
+        self._unconsumed = True
         self._pending = [0, 0]
         self._works = []
         self.views = {p: self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape)
                       for p in self.params}
         return dict(self.views)
+
+    def consume(self):
+        """The gradients of the last backward pass were applied (optimizer.step) or discarded (zero_grad)."""
+        self._unconsumed = False
 
     def bind_param_grads(self):
         """Make every `p.grad` the parameter's view of the flat buffer.  Autograd only *sometimes* keeps the tensor a

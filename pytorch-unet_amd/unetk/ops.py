@@ -90,7 +90,33 @@ class ZeroArena:
         return t
 
 
-_ARENA = ZeroArena()
+class _ArenaMap:
+    """One ZeroArena per (device, stream): reuse of a slice is ordered only by the stream that zeroed and consumed it,
+    so two streams (or two GPUs driven from one process) must never share a buffer."""
+
+    def __init__(self):
+        self.arenas = {}
+
+    def _current(self, device, create):
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            return None
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        a = self.arenas.get(key)
+        if a is None and create:
+            a = self.arenas[key] = ZeroArena()
+        return a
+
+    def begin(self, device, n_doubles):
+        self._current(device, True).begin(device, n_doubles)
+
+    def take(self, n_doubles, device):
+        a = self._current(device, False)
+        return a.take(n_doubles, device) if a is not None else None
+
+
+_ARENA = _ArenaMap()
 
 
 def begin_stats_arena(device, total_channels):
@@ -202,8 +228,11 @@ _WS = {}
 
 
 def workspace(nbytes, device, tag='ws'):
-    """Per-(device, tag) grow-only scratch buffer (stream-ordered reuse on the current stream)."""
-    key = (str(device), tag)
+    """Per-(device, stream, tag) grow-only scratch buffer: reuse is ordered by the stream the kernels run on, so each
+    stream gets its own."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -21,7 +21,66 @@ class ClipRMSprop(torch.optim.Optimizer):
                                                  momentum=momentum, max_norm=max_norm))
         self.pflat = self.square_avg = self.momentum_buf = None
         self.total_norm = None          # device fp64 scalar: ||grad||_2 before clipping (clip_grad_norm_'s result)
+        self._steps = 0
         self._flatten()
+
+    def zero_grad(self, set_to_none=True):
+        """train.py:113.  The flat gradient buffer is rewritten by every backward pass, so there is nothing to zero;
+        the call marks the previous pass's gradients as discarded (a backward without it or step() in between would be
+        gradient accumulation, which the flat buffer does not do: FlatGrads.initial_grads raises)."""
+        self.fg.consume()
+        super().zero_grad(set_to_none=set_to_none)
+
+    # ---- checkpoint / resume in torch.optim.RMSprop's own format (train.py saves only the model's state_dict, but a
+    # user who checkpoints the optimizer can move between the two): per-parameter 'step', 'square_avg',
+    # 'momentum_buffer', keyed by the parameter's index in the group
+    def state_dict(self):
+        g = self.param_groups[0]
+        group = {k: v for k, v in g.items() if k != 'params'}
+        group.update(centered=False, params=list(range(len(self.fg.params))))
+        state = {}
+        if self._steps > 0:
+            for i, p in enumerate(self.fg.params):
+                off, n = self.fg.offsets[id(p)], p.numel()
+                st = {'step': torch.tensor(float(self._steps)),
+                      'square_avg': self.square_avg[off:off + n].view(p.shape).clone()}
+                if g['momentum'] > 0:
+                    st['momentum_buffer'] = self.momentum_buf[off:off + n].view(p.shape).clone()
+                state[i] = st
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.fg.params):
+            raise ValueError('ClipRMSprop.load_state_dict: expected one parameter group over the same parameters')
+        if groups[0].get('centered', False):
+            raise ValueError('ClipRMSprop.load_state_dict: centered RMSprop state cannot be loaded')
+        g = self.param_groups[0]
+        for k in ('lr', 'alpha', 'eps', 'weight_decay', 'momentum', 'max_norm'):
+            if k in groups[0]:
+                g[k] = groups[0][k]
+        self.square_avg.zero_()
+        self.momentum_buf.zero_()
+        steps = 0
+        # the parameters are listed in gradient-completion order here and in module order in a stock optimizer: match
+        # by position only when the saved indices came from this class (same order) -- torch's checkpoints are matched
+        # through `param_names` when present, else by position in net.parameters() order
+        order = self._saved_order(groups[0])
+        for i, st in state_dict['state'].items():
+            p = order[int(i)]
+            off, n = self.fg.offsets[id(p)], p.numel()
+            if tuple(st['square_avg'].shape) != tuple(p.shape):
+                raise ValueError('ClipRMSprop.load_state_dict: state shape does not match the parameter')
+            self.square_avg[off:off + n].view(p.shape).copy_(st['square_avg'])
+            if 'momentum_buffer' in st and st['momentum_buffer'] is not None:
+                self.momentum_buf[off:off + n].view(p.shape).copy_(st['momentum_buffer'])
+            steps = max(steps, int(float(st.get('step', 0))))
+        self._steps = steps
+
+    def _saved_order(self, group):
+        if 'max_norm' in group:          # written by this class: gradient-completion order
+            return self.fg.params
+        return list(self.fg.module_order)
 
     def _flatten(self):
         """(Re-)point every parameter at its slice of one flat buffer; optimizer state survives a re-flatten."""
@@ -68,4 +127,6 @@ class ClipRMSprop(torch.optim.Optimizer):
         # the kernel wrote the parameters behind PyTorch's back: bump their version counters like any in-place op
         # would, so autograd's checks and the packed-weight cache (blocks.packed_weight) see the update
         torch.autograd.graph.increment_version(self.fg.params)
+        self._steps += 1
+        self.fg.consume()
         return None

@@ -50,4 +50,5 @@ class Trainer:
             # the flat buffer (averaged over ranks, clipped) is authoritative: hand its views to torch's optimizer
             self.sync.bind_param_grads()
         self.optimizer.step()
+        self.sync.consume()
         return loss.detach()

@@ -538,3 +538,22 @@ def test_bn_relu_apply_head_equals_apply_then_conv1x1(dtype, ncls, npix_shape):
     assert torch.equal(act, ref_act)
     assert torch.equal(cat[..., c:].float(), torch.full((n, h, w, 64), 5.0, device='cuda'))
     assert logits.shape == ref_logits.shape and torch.equal(logits, ref_logits)
+
+
+def test_scratch_buffers_are_per_stream():
+    """The zeroed statistics arena and the grow-only workspace are reused in stream order, so every stream has its own."""
+    from unetk import ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ops.begin_stats_arena(dev, 64)
+    a = ops.new_stats(64, dev)
+    wa = ops.workspace(4096, dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.begin_stats_arena(dev, 64)
+        b = ops.new_stats(64, dev)
+        wb = ops.workspace(4096, dev)
+    assert a.data_ptr() != b.data_ptr() and wa.data_ptr() != wb.data_ptr()
+    ops.begin_stats_arena(dev, 64)
+    assert ops.new_stats(64, dev).data_ptr() == a.data_ptr()         # same stream: the same slice again
+    assert ops.workspace(4096, dev).data_ptr() == wa.data_ptr()
+    torch.cuda.synchronize()

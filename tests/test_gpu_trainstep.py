@@ -112,7 +112,7 @@ def test_literal_reference_train_loop_runs_unchanged(amp):
     opt = torch.optim.RMSprop(net.parameters(), lr=lr, weight_decay=1e-8, momentum=0.999, foreach=True)
     loss = _reference_loop_body(net, opt, torch.nn.CrossEntropyLoss(),
                                 img.cuda().to(memory_format=torch.channels_last), mask.cuda(), amp, dice_loss)
-    assert abs(float(loss) - float(rloss)) < (2e-2 if amp else 1e-4)
+    assert abs(float(loss) - float(rloss.detach())) < (2e-2 if amp else 1e-4)
     got = dict(net.named_parameters())
     rp = dict(ref.named_parameters())
     # the first RMSprop step moves element i by lr * g_i / (sqrt(0.01 g_i^2) + eps) ~ 10 lr sign(g_i): a sign-like
@@ -157,3 +157,50 @@ def test_unfused_trainer_channels_last_clip_reaches_every_gradient():
     pa, pb = dict(nets[0].named_parameters()), dict(nets[1].named_parameters())
     for k in pa:
         assert l2_err(npy(pa[k]), npy(pb[k])) < 5e-3, k
+
+
+def test_fused_optimizer_state_dict_is_rmsprops_and_accumulation_is_refused():
+    """ClipRMSprop checkpoints in torch.optim.RMSprop's format: after two steps its state loads into a stock RMSprop
+    (and back) and both continue with the same third step.  A second backward without step()/zero_grad() raises
+    instead of silently dropping the first pass's gradients."""
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    from unetk.trainer import Trainer
+    img = _img()
+    mask = torch.from_numpy(W.int_wave(TAG + '.mask', (SHAPE[0],) + SHAPE[2:], 2)).cuda()
+    kw = dict(amp=False, learning_rate=1e-3, gradient_clipping=1.0)
+    nets = [_closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train() for _ in range(3)]
+    ta = Trainer(nets[0], fused_optimizer=True, **kw)
+    for _ in range(2):
+        ta.step(img, mask)
+    sd = ta.optimizer.state_dict()
+    assert set(sd['state'][0]) == {'step', 'square_avg', 'momentum_buffer'} and float(sd['state'][0]['step']) == 2.0
+    # (a) into a second fused trainer on a copy of the parameters
+    nets[1].load_state_dict(nets[0].state_dict())
+    tb = Trainer(nets[1], fused_optimizer=True, **kw)
+    tb.optimizer.load_state_dict(sd)
+    # (b) a stock RMSprop checkpoint (module parameter order) into a third
+    nets[2].load_state_dict(nets[0].state_dict())
+    stock = torch.optim.RMSprop(nets[2].parameters(), lr=1e-3, weight_decay=1e-8, momentum=0.999, foreach=True)
+    by_param = {p: sd['state'][i] for i, p in enumerate(ta.sync.params)}
+    own = dict(zip(nets[0].parameters(), nets[2].parameters()))
+    for p0, p2 in own.items():
+        stock.state[p2] = {k: v.clone() for k, v in by_param[p0].items()}
+    tc = Trainer(nets[2], fused_optimizer=True, **kw)
+    tc.optimizer.load_state_dict(stock.state_dict())
+    la, lb, lc = float(ta.step(img, mask)), float(tb.step(img, mask)), float(tc.step(img, mask))
+    assert abs(la - lb) <= 1e-6 * abs(la) and abs(la - lc) <= 1e-6 * abs(la)
+    pa = dict(nets[0].named_parameters())
+    for other in (nets[1], nets[2]):
+        for k, p in other.named_parameters():
+            assert l2_err(npy(p), npy(pa[k])) < 1e-5, k
+    # ---- accumulation
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=False):
+        loss = segmentation_loss(nets[0](img), mask)
+    loss.backward()
+    loss2 = segmentation_loss(nets[0](img), mask)
+    with pytest.raises(RuntimeError, match='accumulation'):
+        loss2.backward()
+    ta.optimizer.zero_grad()
+    segmentation_loss(nets[0](img), mask).backward()                 # fine again after zero_grad()
+    ta.optimizer.step()
