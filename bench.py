@@ -167,6 +167,7 @@ def dry_run(args, rank, world):
                 grads[p].fill_(float(rank + 1))
             sync.ready(blk, grads)
         sync.finish()
+        sync.consume()                                  # the optimizer step of the real loop
         return grads
 
     for _ in range(args.warmup):

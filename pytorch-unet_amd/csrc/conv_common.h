@@ -47,17 +47,7 @@ struct ConvParams {
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
   static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
-#ifdef UNETK_EXP_MFMA16
-    // PERF PROBE ONLY (wrong numerics): the same fragments, FLOPs and matrix-pipe cycles as one 32x32x16 through two
-    // 16x16x32 instructions -- does the chip hold a higher clock on that shape (MI355X_MICROARCH DVFS item 7)?
-    f32x4 c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { c[i] = c0[i]; c[4 + i] = c1[i]; }
-#else
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
   }
 };
 template <> struct Mma<float> {

@@ -46,20 +46,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds0, const char* lds1) {
 __device__ __forceinline__ int swz(int p) { return ((p >> 1) & 1) << 2; }
 
 
-#ifdef UNETK_EXP_MFMA16
-// PERF PROBE ONLY (wrong numerics): same fragments, FLOPs and matrix-pipe cycles through two 16x16x32 instructions
-__device__ __forceinline__ f32x16 probe_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-  f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { c[i] = c0[i]; c[4 + i] = c1[i]; }
-  return c;
-}
-#define WG_MFMA(a, b, c) probe_mfma(a, b, c)
-#else
 #define WG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
 
 template <int MODE>   // 0 conv3x3, 1 convT2x2
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
