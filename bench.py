@@ -292,29 +292,37 @@ def main(argv=None):
             step()
             torch.cuda.synchronize()
         table = kt.summary()
-        n_l, ms, fl = 0, 0.0, 0.0
-        names = ('unetk_conv3x3_fprop', 'unetk_conv3x3_dgrad', 'unetk_conv3x3_dgrad_sums', 'unetk_conv3x3_dgrad_bn_reduce',
-                 'unetk_conv3x3_fprop_bn_relu')
-        for name in names:
-            if name in table:
-                n_l += table[name][0]
-                ms += table[name][1]
-                fl += table[name][2]
+        # the conv3x3 fprop/dgrad launches of the step by the device kernel that served them; the roofline object is the
+        # DOMINANT kernel's (conv3x3_db_kernel: its rocprofv3 --kernel-trace row must show the same average duration),
+        # the whole family (with the 16x16x32 kernels of the 64-channel n-tiles) rides along as `conv3x3_family`
+        per_kernel = kt.by_device_kernel()
+        n_l, ms, fl, alg_bytes = per_kernel.get('conv3x3_db_kernel', (0, 0.0, 0.0, 0.0))
+        fam = [sum(v[i] for v in per_kernel.values()) for i in range(3)]
         if ms > 0:
             achieved = fl / (ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype_name]
+            tname = 'bf16' if cfg['amp'] else 'float'
             roofline = {'bound': 'mfma',
-                        'kernel': f'conv3x3_db_kernel<{"bf16" if cfg["amp"] else "float"}> (the conv3x3 fprop'
-                                  f'{" + dgrad" if cfg["train"] else ""} launches of one step; 128-channel NB=4 and '
-                                  '64-channel instantiations)',
+                        'kernel': f'conv3x3_db_kernel<{tname}> (conv3x3 fprop{" + dgrad" if cfg["train"] else ""} '
+                                  'launches of one step with GEMM-N a multiple of 128'
+                                  f'{"" if cfg["amp"] else "; fp32: every conv3x3 launch"})',
                         'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': peak,
-                        'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None}
+                        'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                        'algorithmic_bytes_per_launch': alg_bytes / n_l,
+                        'conv3x3_family': {
+                            'kernels': {k: {'launches': v[0], 'avg_launch_ms': v[1] / v[0],
+                                            'achieved': v[2] / (v[1] * 1e-3) / 1e12,
+                                            'frac': v[2] / (v[1] * 1e-3) / 1e12 / peak} for k, v in per_kernel.items()},
+                            'launches_per_step': fam[0], 'achieved': fam[2] / (fam[1] * 1e-3) / 1e12,
+                            'frac': fam[2] / (fam[1] * 1e-3) / 1e12 / peak,
+                            'note': 'conv3x3_k32 = conv3x3_k32n64_kernel / conv3x3_k32_kernel (64-channel n-tiles); the two '
+                                    'fused dgrad + BN-backward-reduce launches are counted with their conv FLOPs only'}}
             if args.config == 'train959' and (hh, ww, B) == (H, W, 16):
                 # counters of THIS command from committed --pmc passes; only quoted for the configuration they were
                 # taken on, with their source
                 tr = committed_profile('*_conv_traffic.json', lambda d: d.get('hbm_bytes_per_launch'))
                 mb = committed_profile('*_mfma_util.json',
-                                       lambda d: (d.get('conv3x3_fprop_dgrad') or d.get('conv3x3_db_kernel', {})).get('mfma_busy_fraction'))
+                                       lambda d: d.get('conv3x3_db_kernel', {}).get('mfma_busy_fraction'))
                 if tr:
                     roofline['traffic'] = tr['value']
                     roofline['traffic_source'] = tr['source']

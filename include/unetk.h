@@ -139,6 +139,9 @@ int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void*
  * unetk_bn_relu_bwd_reduce would form from dx and z_prev -- `sums` [UNETK_STAT_REPLICAS][c_in][2] doubles zeroed by the
  * caller; scale/shift/mean/invstd: that layer's BatchNorm state [c_in].  Shapes whose kernel has no such epilogue run
  * dgrad followed by unetk_bn_relu_bwd_reduce; the result is the same either way. */
+/* 1 when the call below folds the reduction into the dgrad kernel for these channel counts, 0 when it runs the two
+ * kernels one after the other (a caller that times or schedules the passes itself may then prefer to call them). */
+int unetk_conv3x3_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype);
 int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
                                   int dx_choff, const void* z_prev, int ldz, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,

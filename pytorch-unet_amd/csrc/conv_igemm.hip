@@ -1062,6 +1062,12 @@ int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void*
   return conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, sums, n, h, w, c_out, c_in, dtype, stream);
 }
 
+int unetk_conv3x3_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype) {
+  // mirrors dispatch<0> / unetk_internal_conv3x3_k32: GEMM-N = c_in, GEMM-K = c_out
+  if (dtype != UNETK_BF16 || c_in <= 0 || c_out < 64 || c_out % 32 != 0) return 0;
+  return conv3_use_k32(1, c_in) && conv3_k32_nb16(c_in) == 4 && c_in == 64 && !getenv("UNETK_K32_NOPIPE");
+}
+
 int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
                                   int dx_choff, const void* z_prev, int ldz, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,

@@ -125,6 +125,38 @@ class KernelTimer:
             return 2.0 * a[8] * a[9] * a[10] * 4 * a[11] * a[12]
         return 0.0
 
+    @staticmethod
+    def _device_kernel(name, a):
+        """Which conv3x3 kernel serves a launch (csrc/conv_config.h: conv3_use_k32): the 16x16x32 kernels take the bf16
+        launches whose GEMM-N is not a multiple of 128, conv3x3_db_kernel everything else."""
+        pos = {'unetk_conv3x3_fprop': (12, 13), 'unetk_conv3x3_dgrad_sums': (11, 13), 'unetk_conv3x3_dgrad': (10, 12),
+               'unetk_conv3x3_dgrad_bn_reduce': (17, 19), 'unetk_conv3x3_fprop_bn_relu': (15, 16)}.get(name)
+        if pos is None:
+            return None
+        n_gemm, dtype = a[pos[0]], a[pos[1]]
+        return 'conv3x3_k32' if (dtype == BF16 and n_gemm % 128 != 0) else 'conv3x3_db_kernel'
+
+    @staticmethod
+    def _conv_bytes(name, a):
+        """Algorithmic bytes of a conv3x3 fprop/dgrad launch: input + output tensor + weights, once each."""
+        pos = {'unetk_conv3x3_fprop': (8, 13), 'unetk_conv3x3_dgrad_sums': (8, 13), 'unetk_conv3x3_dgrad': (7, 12),
+               'unetk_conv3x3_dgrad_bn_reduce': (14, 19), 'unetk_conv3x3_fprop_bn_relu': (11, 16)}.get(name)
+        if pos is None:
+            return 0.0
+        n, h, w, c_in, c_out = a[pos[0]:pos[0] + 5]
+        es = 2 if a[pos[1]] == BF16 else 4
+        return float(es) * (n * h * w * (c_in + c_out) + 9 * c_in * c_out)
+
+    def by_device_kernel(self):
+        """{device kernel: (launches, total_ms, total_flops, total_algorithmic_bytes)} over the conv3x3 fprop/dgrad
+        launches."""
+        out = {}
+        for name, s, e, fl, kern, nbytes in self.records:
+            if kern is not None:
+                n, ms, f, b = out.get(kern, (0, 0.0, 0.0, 0.0))
+                out[kern] = (n + 1, ms + s.elapsed_time(e), f + fl, b + nbytes)
+        return out
+
     def __enter__(self):
         self._saved = dict(fn)
         for name, raw in self._saved.items():
@@ -136,7 +168,8 @@ class KernelTimer:
                 s.record()
                 rc = _raw(*args)
                 e.record()
-                self.records.append((_name, s, e, self._flops(_name, args)))
+                self.records.append((_name, s, e, self._flops(_name, args), self._device_kernel(_name, args),
+                                     self._conv_bytes(_name, args)))
                 return rc
             fn[name] = timed
         return self
@@ -148,7 +181,7 @@ class KernelTimer:
     def summary(self):
         """{name: (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for name, s, e, fl in self.records:
+        for name, s, e, fl, _, _ in self.records:
             n, ms, f = out.get(name, (0, 0.0, 0.0))
             out[name] = (n + 1, ms + s.elapsed_time(e), f + fl)
         return out

@@ -240,7 +240,8 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
 def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
     seq = dc.double_conv
     s1, s2 = saved
-    if FUSE_BN_REDUCE:
+    c_mid = seq[3].in_channels
+    if FUSE_BN_REDUCE and ops.dgrad_bn_reduce_is_fused(c_mid, seq[3].out_channels, s1[1].dtype):
         # s1 = (x, z1, state1): the second conv consumed relu(bn(z1)), so its dgrad epilogue can reduce for BN 1
         da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead,
                                       bn_prev=(s1[1], s1[2]))

@@ -174,6 +174,12 @@ def conv3x3_fprop_bn_relu(x, wpk, c_out, state, out=None, pool_out=None):
     return out
 
 
+def dgrad_bn_reduce_is_fused(c_in, c_out, dtype):
+    """Does conv3x3_dgrad(bn_prev=...) fold the reduction into the dgrad kernel for this layer (else it would run the
+    two kernels back to back inside one call: same result, nothing saved)?"""
+    return bool(fn['unetk_conv3x3_dgrad_bn_reduce_is_fused'](int(c_in), int(c_out), dtype_code(dtype)))
+
+
 def conv3x3_dgrad(dy, wpk_d, c_in, out=None, sums=None, bn_prev=None):
     """sums: optional zeroed fp64 [REPLICAS, c_in, 2] that receives the per-channel sums of the written gradient
     (the conv epilogue's fused statistics; used for the ConvTranspose2d bias gradient).

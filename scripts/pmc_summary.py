@@ -60,11 +60,16 @@ def main():
         f.write('kernel,launches,read_bytes_per_launch(2xFETCH_SIZE),write_bytes_per_launch(WRITE_SIZE),total_GB_all_launches\n')
         for k, n, fb, wb in rows:
             f.write(f'"{k}",{n},{fb:.0f},{wb:.0f},{(fb + wb) * n / 1e9:.3f}\n')
-    conv = [r for r in rows if r[0].startswith(('conv3x3_db_kernel', 'conv3x3_k32n64_kernel', 'conv3x3_k32_kernel'))]
+    fam = [r for r in rows if r[0].startswith(('conv3x3_db_kernel', 'conv3x3_k32n64_kernel', 'conv3x3_k32_kernel'))]
+    conv = [r for r in rows if r[0].startswith('conv3x3_db_kernel')]
     n = sum(r[1] for r in conv)
     tot = sum((r[2] + r[3]) * r[1] for r in conv)
-    out = {'kernel': 'conv3x3_db_kernel + conv3x3_k32n64_kernel (all instantiations: fprop + dgrad launches)', 'launches': n,
+    nf = sum(r[1] for r in fam)
+    totf = sum((r[2] + r[3]) * r[1] for r in fam)
+    out = {'kernel': 'conv3x3_db_kernel (all instantiations: the fprop + dgrad launches with GEMM-N % 128 == 0)', 'launches': n,
            'hbm_bytes_per_launch': tot / max(n, 1),
+           'family': {'kernel': 'conv3x3_db_kernel + conv3x3_k32n64_kernel + conv3x3_k32_kernel', 'launches': nf,
+                      'hbm_bytes_per_launch': totf / max(nf, 1)},
            'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 '
                      '--warmup 1`; bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: 128-B read requests are tallied as 64 B)'}
     with open(prefix + '_conv_traffic.json', 'w') as f:
