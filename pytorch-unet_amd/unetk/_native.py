@@ -160,8 +160,8 @@ class KernelTimer:
     def __enter__(self):
         self._saved = dict(fn)
         for name, raw in self._saved.items():
-            if PROTOTYPES[name][1] is not ctypes.c_int or not PROTOTYPES[name][0]:
-                continue
+            if PROTOTYPES[name][1] is not ctypes.c_int or not PROTOTYPES[name][0] or name.endswith('_is_fused'):
+                continue                                   # size / capability queries launch nothing
 
             def timed(*args, _raw=raw, _name=name):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
