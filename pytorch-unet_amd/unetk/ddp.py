@@ -97,15 +97,23 @@ class FlatGrads:
         lo, hi = self._pending
         if hi > lo:
             op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
-            self._works.append((dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True), lo, hi))
+            buf = self.flat[lo:hi]
+            if not self.native_avg and buf.is_cuda:
+                # gloo (rehearsals without RCCL, e.g. two ranks sharing one GPU): its collectives on device tensors
+                # hang on this ROCm stack, so the bucket is staged through the host -- same bucket ranges, same launch
+                # points inside the backward, same wait-before-clip; only the overlap is lost
+                buf = buf.cpu()
+            self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), lo, hi, buf))
         self._pending = [hi, hi]
 
     def finish(self):
         """Call after backward(): flush the last bucket and make the compute stream wait for every all-reduce."""
         if self.active:
             self._launch()
-            for w, lo, hi in self._works:
+            for w, lo, hi, buf in self._works:
                 w.wait()
+                if buf.device != self.flat.device:
+                    self.flat[lo:hi].copy_(buf)
                 if not self.native_avg:
                     self.flat[lo:hi].div_(self.world)
         self._works = []
