@@ -154,10 +154,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
     glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
   // weight fragment q of the stage that starts at fragment `frag0` of chunk `chunk` and has `nfrag` fragments
-  auto issue_weight = [&](int q, int chunk, int frag0, int nfrag, unsigned buf, bool live) {
+  // (branch-free as well: `live` is wave-uniform and a ?: over whole addresses becomes an s_cbranch that splits the MFMA
+  // block -- the stage's base is selected once by the caller, the lane offset is masked)
+  auto issue_weight = [&](int q, const char* src_base, unsigned live_mask, int nfrag, unsigned buf) {
     const int fi = min(q * NW + wid, nfrag - 1);
-    const char* src = live ? wbase + ((size_t)chunk * (TAPS * NB16) + frag0 + fi) * 1024 + lane * 16 : zero;
-    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    glds16_hidden(src_base + ((unsigned)(fi * 1024 + lane * 16) & live_mask), __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
 
   f32x4v acc[MB][2][NB16];
@@ -183,12 +184,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
       if (st < nst) {
         const int chunk = st / NSTAGE, s_in = st % NSTAGE;
         const int frag0 = s_in == 0 ? 0 : STEPS0 * NB16, nfrag = (s_in == 0 ? STEPS0 : TAPS - STEPS0) * NB16;
-        for (int q = 0; q * NW < nfrag; ++q) issue_weight(q, chunk, frag0, nfrag, ldsw0 + st * W_BYTES, true);
+        for (int q = 0; q * NW < nfrag; ++q)
+          issue_weight(q, wbase + ((size_t)chunk * (TAPS * NB16) + frag0) * 1024, ~0u, nfrag, ldsw0 + st * W_BYTES);
       }
     }
   } else {
 #pragma unroll
-    for (int q = 0; q * NW < STEPS0 * NB16; ++q) issue_weight(q, 0, 0, STEPS0 * NB16, ldsw0, true);
+    for (int q = 0; q * NW < STEPS0 * NB16; ++q) issue_weight(q, wbase, ~0u, STEPS0 * NB16, ldsw0);
   }
   // BN statistics of all tiles of this workgroup: per tile in registers; across tiles in registers too, or (LDSSTATS)
   // in an LDS array [BN][2] behind the staging buffers by ds_add_f32
@@ -250,9 +252,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
         constexpr int in_pieces = (st + 1 == NSTAGE) ? IN_PER_WAVE - in_q0 : IN_PER_ST;
         constexpr int ndma = in_pieces + w_pieces;
         constexpr int pps = (ndma + nsteps - 1) / nsteps;      // DMA pieces per k-step
+        const char* wsrc = live_w ? wbase + ((size_t)next_wc * (TAPS * NB16) + frag0_next) * 1024 : zero;
+        const unsigned wmask = live_w ? ~0u : 0u;
         auto issue_piece = [&](int q) {
           if (q < in_pieces) issue_input(in_q0 + q, next_in, nbuf_in, live_in);
-          else issue_weight(q - in_pieces, next_wc, frag0_next, nfrag_next, nbuf_w, live_w);
+          else issue_weight(q - in_pieces, wsrc, wmask, nfrag_next, nbuf_w);
         };
 
         {
