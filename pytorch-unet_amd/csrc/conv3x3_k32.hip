@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       if (st < nst)
         for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, wbase + (size_t)st * W_BYTES, ~0u, ldsw0 + st * W_BYTES);
   }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int curi = 0, curw = 0;
 
   // BNR: z of the producer layer for the tile in flight, [row][pixel set][pixel] x 4 adjacent channels (packed), and

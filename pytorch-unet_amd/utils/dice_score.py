@@ -28,7 +28,7 @@ class _DiceFn(torch.autograd.Function):
 
 
 def dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):
-    # Average of Dice coefficient for all batches, or for a single mask
+    # one Dice value per reduction group (a mask, or a whole batch of masks), averaged
     assert input.size() == target.size()
     assert input.dim() == 3 or not reduce_batch_first
     if not input.is_cuda:
@@ -48,11 +48,11 @@ def dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, 
 
 
 def multiclass_dice_coeff(input: Tensor, target: Tensor, reduce_batch_first: bool = False, epsilon: float = 1e-6):
-    # Average of Dice coefficient for all classes
+    # classes fold into the batch dimension: every (image, class) plane is its own group
     return dice_coeff(input.flatten(0, 1), target.flatten(0, 1), reduce_batch_first, epsilon)
 
 
 def dice_loss(input: Tensor, target: Tensor, multiclass: bool = False):
-    # Dice loss (objective to minimize) between 0 and 1
+    # 1 - Dice: 0 for a perfect overlap
     fn = multiclass_dice_coeff if multiclass else dice_coeff
     return 1 - fn(input, target, reduce_batch_first=True)
