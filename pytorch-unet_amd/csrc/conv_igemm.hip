@@ -639,10 +639,13 @@ int launch_db(const ConvParams& P, hipStream_t s) {
 //          out 3,3,3,1 between the k-steps; one barrier per chunk
 //   MODE 1 epilogue: + bias, pixel-shuffle store (tap = channel / Co) into the concat buffer at a channel offset
 //   MODE 2 operand:  per tap the stride-2 gather of the up-sampled gradient (per-lane DMA source addresses)
-template <typename T, int MODE>
-__global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
+// NW / KS: 8 waves and 64-channel chunks (160 KiB: one workgroup per CU), or -- the shallow, HBM-bound levels -- 4 waves
+// and 32-channel chunks (48 KiB): then two or three INDEPENDENT workgroups share a CU and one's epilogue stores run
+// under another's DMA and MFMA phases.  The packed weight stream is the same for both (k-steps in order, NB inner).
+template <typename T, int MODE, int NW = 8, int KS = 4>
+__global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
   constexpr int E = ElemTraits<T>::E;
-  constexpr int NB = 4, KS = 4, NW = 8;
+  constexpr int NB = 4;
   constexpr int NP = 2 * KS, CH = NP * E, S = 32 * KS;
   constexpr int TP = 64 * NW;                     // pixels per tile
   constexpr int IN_INSTR = TP * S / 1024;         // 64
@@ -890,21 +893,22 @@ __global__ __launch_bounds__(512) void pw_db_kernel(ConvParams P) {
   }
 }
 
-template <typename T, int MODE> int launch_pw(const ConvParams& P, hipStream_t s) {
-  constexpr size_t lds = 2 * (64 * 1024 + 16 * 1024);
-  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE>), lds);
+template <typename T, int MODE, int NW = 8, int KS = 4> int launch_pw(const ConvParams& P, hipStream_t s) {
+  constexpr size_t lds = 2 * ((size_t)64 * NW * 32 * KS + KS * 4 * 1024);
+  constexpr int WG_PER_CU = NW == 8 ? 1 : (160 * 1024) / (int)lds > 2 ? 2 : (160 * 1024) / (int)lds;   // VGPRs: 8 waves per CU
+  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS>), lds);
   ConvParams Q = P;
   Q.n_tiles = P.Cout / 128;
   const long npix = (long)P.N * P.H * P.W;
-  const long ntiles = (npix + 511) / 512;
-  const int niter = (P.Cin / (8 * ElemTraits<T>::E)) * (MODE == 2 ? 4 : 1);
-  // one workgroup per CU: tiles per workgroup by the round model of launch_db (whole rounds of 256 workgroups)
+  const long ntiles = (npix + 64 * NW - 1) / (64 * NW);
+  const int niter = (P.Cin / (2 * KS * ElemTraits<T>::E)) * (MODE == 2 ? 4 : 1);
+  // tiles per workgroup by the round model of launch_db (whole rounds of resident workgroups)
   int tpb = 1;
   {
     double best = 1e30;
     for (int t = 1; t <= 16; ++t) {
       const long wgs = ((ntiles + t - 1) / t) * Q.n_tiles;
-      const long rounds = (wgs + 255) / 256;
+      const long rounds = (wgs + 256 * WG_PER_CU - 1) / (256 * WG_PER_CU);
       const double cost = (double)rounds * ((double)t * niter + 1.5);
       if (cost < best * 0.999) { best = cost; tpb = t; }
     }
@@ -915,7 +919,7 @@ template <typename T, int MODE> int launch_pw(const ConvParams& P, hipStream_t s
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
   Q.nblk = (int)nblk;
-  hipLaunchKernelGGL((pw_db_kernel<T, MODE>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(512), lds, s, Q);
+  hipLaunchKernelGGL((pw_db_kernel<T, MODE, NW, KS>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(64 * NW), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -973,6 +977,10 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
   }
   if constexpr (MODE != 0) {
     if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)
+      // GEMM-K up to 1024: 4-wave workgroups, two per CU (measured at the four decoder levels: forward 0.48 -> 0.41,
+      // 0.35 -> 0.31, 0.23 -> 0.20, 0.22 -> 0.21 ms; dgrad 0.42 -> 0.40, 0.30 -> 0.29 ms; K = 2048 dgrad 0.21 -> 0.22)
+      static const int small = getenv("UNETK_PW_SMALL") ? atoi(getenv("UNETK_PW_SMALL")) : 1024;
+      if (dtype == UNETK_BF16 && P.Cin * (MODE == 2 ? 4 : 1) <= small) return launch_pw<bf16, MODE, 4, 2>(P, s);
       if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
       return UNETK_ERR_DTYPE;
