@@ -32,6 +32,16 @@ def main():
     f = glob.glob(os.path.join(src, 'pmc_fetch', '**', '*counter_collection.csv'), recursive=True)[0]
     w = glob.glob(os.path.join(src, 'pmc_write', '**', '*counter_collection.csv'), recursive=True)[0]
     subprocess.run([py, os.path.join(ROOT, 'scripts', 'pmc_summary.py'), f, w, dst], check=True)
+    # stamp the two files bench.py quotes counters from with the source state they were measured on
+    import json
+    sha = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(['git', '-C', ROOT, 'status', '--porcelain', '--', 'pytorch-unet_amd', 'bench.py'],
+                           capture_output=True, text=True).stdout.strip()
+    for name in ('mfma_util.json', 'conv_traffic.json'):
+        path = f'{dst}_{name}'
+        doc = json.load(open(path))
+        doc['commit'] = sha + ('+uncommitted changes' if dirty else '')
+        json.dump(doc, open(path, 'w'), indent=1)
 
 
 if __name__ == '__main__':
