@@ -7,7 +7,8 @@ from unetk import ops
 N = int(os.environ.get('N', 16))
 layers = [(640, 959, 64, 64), (640, 959, 128, 64), (320, 479, 64, 128), (320, 479, 128, 128), (320, 479, 256, 128),
           (160, 239, 128, 256), (160, 239, 256, 256), (160, 239, 512, 256), (80, 119, 256, 512), (80, 119, 512, 512),
-          (80, 119, 1024, 512), (40, 59, 512, 1024), (40, 59, 1024, 1024)]
+          (80, 119, 1024, 512), (40, 59, 512, 1024), (40, 59, 1024, 1024),
+          (640, 959, 64, 128)]          # the shape of up4's first conv as a dgrad (GEMM-K 64, GEMM-N 128)
 if os.environ.get('ONLY'):
     layers = [layers[int(i)] for i in os.environ['ONLY'].split(',')]
 dt = torch.bfloat16 if os.environ.get('DT', 'bf16') == 'bf16' else torch.float32
