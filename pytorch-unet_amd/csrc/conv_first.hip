@@ -165,8 +165,39 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
     T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
     const int lane_off = 4 * h * P.ldy + ch0;
     const int xl = x0 + 4 * h;
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+      // interior tiles, training path: as in conv3x3_db_kernel -- round once into packed pixel pairs, statistics by
+      // v_dot2c_f32_bf16, the two-channel store words gathered with v_perm, no per-element predicates
+      if (!aff && (y0 + 8 <= P.H) && (x0 + 32 <= P.W)) {
+        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const int yy = y0 + 2 * wid + mb;
+          T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy + lane_off;
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const int ri = (i & 3) + 8 * (i >> 2);
+            unsigned pk[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              const bf16x2 y2 = {(bf16)acc[mb][nb][i], (bf16)acc[mb][nb][i + 1]};
+              pk[nb] = __builtin_bit_cast(unsigned, y2);
+              ssum[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, ssum[nb], false);
+              ssq[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, ssq[nb], false);
+            }
+            __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x05040100u),
+                                        reinterpret_cast<unsigned*>(rowp + ri * P.ldy));
+            __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x07060302u),
+                                        reinterpret_cast<unsigned*>(rowp + (ri + 1) * P.ldy));
+          }
+        }
+        done = true;
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
+      if (done) break;
       const int yy = y0 + 2 * wid + mb;
       T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;
 #pragma unroll
