@@ -239,11 +239,12 @@ def main(argv=None):
     from unetk.trainer import Trainer
 
     torch.manual_seed(0)
-    net = UNet(3, cfg['n_classes'], cfg['bilinear']).to(dev).to(memory_format=torch.channels_last)
-    net = net.train() if cfg['train'] else net.eval()
-    if world > 1:                                    # identical replicas: broadcast rank 0's random init
-        for t in list(net.parameters()) + list(net.buffers()):
+    net = UNet(3, cfg['n_classes'], cfg['bilinear']).to(dev)
+    if world > 1:                                    # identical replicas: broadcast rank 0's random init (while the
+        for t in list(net.parameters()) + list(net.buffers()):   # tensors are still plainly contiguous)
             dist.broadcast(t.data, 0)
+    net = net.to(memory_format=torch.channels_last)
+    net = net.train() if cfg['train'] else net.eval()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.rand((B, 3, hh, ww), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
     if cfg['n_classes'] == 2:
