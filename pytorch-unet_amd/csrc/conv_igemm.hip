@@ -24,6 +24,13 @@
 #include "conv_common.h"
 #include "conv_config.h"
 
+#ifndef UNETK_DB_PIPE
+#define UNETK_DB_PIPE 1      // conv3x3_db_kernel: single fragment set, mid-step chunk barrier (0: round-2 loop)
+#endif
+#ifndef UNETK_DB_DMAPOS
+#define UNETK_DB_DMAPOS 0    // row-block-1 MFMA of a k-step behind which its DMA piece is issued
+#endif
+
 namespace {
 
 
@@ -434,6 +441,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
     for (int nb = 0; nb < NB; ++nb) { asc[nb] = P.aff_scale[ch0 + nb]; ash[nb] = P.aff_shift[ch0 + nb]; }
   }
 
+#if UNETK_DB_PIPE
+  // ONE fragment register set, each fragment re-read right after the MFMA that used it last; the k-step stream runs
+  // on across weight chunks, input chunks and tiles.  The chunk barrier sits in the MIDDLE of a chunk's last k-step
+  // (after its row-block-0 MFMAs): every wave then holds that step's fragments in registers, i.e. is done reading the
+  // current buffers, and the first fragments of the next chunk are read under the row-block-1 MFMAs like those of any
+  // other step -- no LDS latency is exposed behind a barrier.
+  uint4 fa[MB], fb[NB];
+  {
+    const char* lds_in = smem;
+    const char* lds_w = smem + 2 * IN_BYTES;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) fa[mb] = *reinterpret_cast<const uint4*>(lds_in + aaddr[mb][0]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) fb[nb] = *reinterpret_cast<const uint4*>(lds_w + nb * 1024 + lane * 16);
+  }
+#endif
+
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int ic = 0; ic < nin; ++ic) {
       // the NEXT input chunk (of this tile, or the first of the next tile) is staged while this one is consumed
@@ -444,6 +468,77 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
         if (tile + 1 < tile_end) setup_stage(tile + 1);
         else live_in = false;
       }
+#if UNETK_DB_PIPE
+#pragma unroll
+      for (int sub = 0; sub < R; ++sub) {
+        const int kc = ic * R + sub;
+        const char* lds_in = smem + curi * IN_BYTES;
+        const char* lds_w = smem + 2 * IN_BYTES + curw * W_BYTES;
+        // buffers of the next weight chunk's first k-step
+        const char* nlds_in = (sub + 1 == R) ? smem + (curi ^ 1) * IN_BYTES : lds_in;
+        const char* nlds_w = smem + 2 * IN_BYTES + (curw ^ 1) * W_BYTES;
+        const int nsub = (sub + 1 == R) ? 0 : sub + 1;
+        int next_w = kc + 1;
+        bool live_w = !(P.dbg & 1);
+        if (kc + 1 == nchunks) {
+          next_w = 0;
+          live_w = live_w && (tile + 1 < tile_end);
+        }
+        const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
+        const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
+        constexpr int NSTEP = TAPS * KS;
+        constexpr int DSTEPS = NSTEP - 1;                   // the last k-step carries the barrier instead
+        constexpr int PPS = (NDMA + DSTEPS - 1) / DSTEPS;
+        auto issue_piece = [&](int q) {
+          if (q < IN_PER_SUB) {
+            const int qi = sub * IN_PER_SUB + q;
+            if (qi < IN_PER_WAVE) issue_input(qi, next_in, nbuf_in, live_in);
+          } else {
+            issue_weight(q - IN_PER_SUB, next_w, nbuf_w, live_w);
+          }
+        };
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+          const bool last = st + 1 == NSTEP;
+          // where the fragments of the k-step after this one live
+          const int nst = last ? 0 : st + 1;
+          const int nt_ = nst / KS, nks = nst % KS;
+          const char* rin = last ? nlds_in : lds_in;
+          const char* rw = last ? nlds_w : lds_w;
+          const int rsub = last ? nsub : sub;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[0][nb], fa[0], fb[nb]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (last) {
+            // next chunks landed (this wave's DMAs), every wave holds its last fragments of the current buffers
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+          fa[0] = *reinterpret_cast<const uint4*>(rin + (aaddr[0][nt_] ^ ((rsub * KS + nks) << 5)));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mb = 1; mb < MB; ++mb) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              Mma<T>::run(acc[mb][nb], fa[mb], fb[nb]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (mb == MB - 1) {
+                fb[nb] = *reinterpret_cast<const uint4*>(rw + (nst * NB + nb) * 1024 + lane * 16);
+                if (nb == UNETK_DB_DMAPOS && !last) {
+#pragma unroll
+                  for (int q = st * PPS; q < (st + 1) * PPS && q < NDMA; ++q) issue_piece(q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            fa[mb] = *reinterpret_cast<const uint4*>(rin + (aaddr[mb][nt_] ^ ((rsub * KS + nks) << 5)));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        curw ^= 1;
+      }
+      curi ^= 1;
+    }
+#else
 #pragma unroll
       for (int sub = 0; sub < R; ++sub) {
         const int kc = ic * R + sub;
@@ -503,6 +598,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
       }
       curi ^= 1;
     }
+#endif
 
     // ---- epilogue of this tile.  64-bit address arithmetic only per row block (wave-uniform); an element adds a
     // 32-bit lane offset and a compile-time multiple of the pixel pitch.
