@@ -56,6 +56,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned frag_t;      // one 16-byte
 
 __device__ uint4 g_zero_page_k32[8];
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// 1 KiB of LDS-DMA through a buffer descriptor: lane -> 16 bytes at desc.base + soff + voff (zeros when voff is out of
+// the descriptor's range), LDS destination = lds_addr + lane * 16 (wave-uniform).  Hidden from the compiler like
+// glds16_hidden (common.h); `s_nop 4`: the SGPR operands may be fresh from v_readfirstlane (cdna_hip_programming 5.7).
+__device__ __forceinline__ void bufdma16(unsigned voff, u32x4 desc, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+      : "memory");
+}
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1 (the loop index feeds constexpr contexts)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -105,7 +122,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
 
   const int nin = P.Cin / 32;                                // 32-channel input chunks
   const char* wbase = reinterpret_cast<const char*>(P.wpk) + (size_t)nt * nin * (TAPS * NB16 * 1024);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page_k32);
 
   // A-fragment addresses.  This lane's row reads halo pixel p = p00 + rr*HP + col (rr = mb + tap/3 in 0..3, col =
   // 4 ps + tap%3 in 0..6) at byte (p << 6) + (swz << 4), swz = ((p >> 2) ^ g) & 3.  The linear part is the lane's base
@@ -124,14 +140,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
       else swz_hi |= v << (2 * ((rr - 2) * 8 + col));
     }
 
-  // DMA descriptors of the tile being staged: byte offset of this lane's piece (chunk 0) inside the image (< 4 GiB:
-  // checked by the caller), or ~0u -> zero page
+  // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): a lane whose offset lies outside the
+  // descriptor's range gets ZEROS written to its LDS slot (scripts/microbench/buf_lds_oob.hip), so padding pixels and
+  // ragged edges are the offset ~0u -- no zero page, no per-lane 64-bit source select, no VALU work per piece -- and a
+  // whole dead stream (past the workgroup's last tile) is a descriptor of zero bytes.
+  //   input:   base = the staged tile's image (+ channel offset), range = to the image's end; voffset = this lane's
+  //            pixel/piece (chunk 0), soffset = 64 B per 32-channel chunk
+  //   weights: base = this n-tile's fragment stream; voffset = lane * 16, soffset = fragment * 1 KiB
   unsigned dma_off[IN_PER_WAVE];
-  const char* ximg = nullptr;
+  u32x4 xdesc = {0u, 0u, 0u, 0x00020000u};
+  const unsigned img_bytes = (unsigned)(((size_t)P.H * P.W * P.ldx - P.xoff) * 2);
   auto setup_stage = [&](int tile) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
-    ximg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+    const unsigned long long xa =
+        (unsigned long long)(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+    xdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)xa);
+    xdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
+    xdesc[2] = img_bytes;
 #pragma unroll
     for (int f = 0; f < IN_PER_WAVE; ++f) {
       const int fi = min(f * NW + wid, IN_INSTR - 1);   // surplus slots of the issue grid repeat the last piece
@@ -145,20 +171,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
       dma_off[f] = off;
     }
   };
-  // branch-free DMA issue (a branch inside the MFMA loop ends the basic block and costs a full lgkmcnt(0) wait)
+  u32x4 wdesc;
+  {
+    const unsigned long long wa = (unsigned long long)wbase;
+    wdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)wa);
+    wdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+    wdesc[2] = (unsigned)nin * (TAPS * NB16 * 1024);
+    wdesc[3] = 0x00020000u;
+  }
+  const unsigned wlane = lane * 16;
   auto issue_input = [&](int q, int in_chunk, unsigned buf, bool live) {
     const int fi = min(q * NW + wid, IN_INSTR - 1);
-    // two selects and one 64-bit add (kept branch-free: a branch would split the MFMA block)
-    const bool ok = live && dma_off[q] != ~0u;
-    const char* src = (ok ? ximg : zero) + (ok ? dma_off[q] + (unsigned)in_chunk * 64u : 0u);
-    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    u32x4 d = xdesc;
+    d[2] = live ? d[2] : 0u;
+    bufdma16(dma_off[q], d, (unsigned)in_chunk * 64u, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
-  // weight fragment q of the stage that starts at fragment `frag0` of chunk `chunk` and has `nfrag` fragments
-  // (branch-free as well: `live` is wave-uniform and a ?: over whole addresses becomes an s_cbranch that splits the MFMA
-  // block -- the stage's base is selected once by the caller, the lane offset is masked)
-  auto issue_weight = [&](int q, const char* src_base, unsigned live_mask, int nfrag, unsigned buf) {
+  // weight fragment q of the stage that starts at fragment `frag_base` of the n-tile's stream and has `nfrag` fragments
+  auto issue_weight = [&](int q, unsigned frag_base, bool live, int nfrag, unsigned buf) {
     const int fi = min(q * NW + wid, nfrag - 1);
-    glds16_hidden(src_base + ((unsigned)(fi * 1024 + lane * 16) & live_mask), __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    u32x4 d = wdesc;
+    d[2] = live ? d[2] : 0u;
+    bufdma16(wlane, d, (frag_base + fi) * 1024u, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
 
   f32x4v acc[MB][2][NB16];
@@ -185,12 +218,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
         const int chunk = st / NSTAGE, s_in = st % NSTAGE;
         const int frag0 = s_in == 0 ? 0 : STEPS0 * NB16, nfrag = (s_in == 0 ? STEPS0 : TAPS - STEPS0) * NB16;
         for (int q = 0; q * NW < nfrag; ++q)
-          issue_weight(q, wbase + ((size_t)chunk * (TAPS * NB16) + frag0) * 1024, ~0u, nfrag, ldsw0 + st * W_BYTES);
+          issue_weight(q, (unsigned)(chunk * (TAPS * NB16) + frag0), true, nfrag, ldsw0 + st * W_BYTES);
       }
     }
   } else {
 #pragma unroll
-    for (int q = 0; q * NW < STEPS0 * NB16; ++q) issue_weight(q, wbase, ~0u, STEPS0 * NB16, ldsw0);
+    for (int q = 0; q * NW < STEPS0 * NB16; ++q) issue_weight(q, 0u, true, STEPS0 * NB16, ldsw0);
   }
   // BN statistics of all tiles of this workgroup: per tile in registers; across tiles in registers too, or (LDSSTATS)
   // in an LDS array [BN][2] behind the staging buffers by ds_add_f32
@@ -213,6 +246,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
     for (int cb = 0; cb < NB16; ++cb) { asc[cb] = P.aff_scale[ch0 + cb]; ash[cb] = P.aff_shift[ch0 + cb]; }
   }
 
+  // ONE fragment register set (4 A + NB16 B fragments), each fragment re-read right after the MFMA that used it last;
+  // the k-step stream runs on across stages, chunks and tiles.  The stage barrier sits INSIDE a stage's last k-step,
+  // behind the MFMAs of its first A fragment: every wave then holds that step's fragments in registers (it is done
+  // reading the current buffers), and the first fragments of the next stage are read under the remaining MFMAs of the
+  // step like those of any other step -- no LDS latency is exposed behind a barrier.
+  const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
+  frag_t fa[MB][2], fb[NB16];
+  auto read_a = [&](int mb, int ps, int t, int a_base) {     // A fragment (mb, ps) of tap t from the input buffer at a_base
+    const int rr = mb + t / 3, col = 4 * ps + (t % 3);
+    // (asm volatile: as plain arithmetic the 28 swizzle terms are loop invariants -- hoisted, then spilled)
+    int addr;
+    asm volatile("v_bfe_u32 %0, %1, %2, 2\n\tv_lshl_add_u32 %0, %0, 4, %3"
+                 : "=&v"(addr)
+                 : "v"(rr < 2 ? swz_lo : swz_hi), "n"(2 * ((rr & 1) * 8 + col)), "v"(a_base));
+    fa[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + addr + (rr * HP + col) * 64);
+  };
+  {
+    const int a_base = (int)lds0 + (p00 << 6), w_base = (int)ldsw0 + lane * 16;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) read_a(mb, ps, 0, a_base);
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + cb * 1024);
+  }
+
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int ic = 0; ic < nin; ++ic) {
       // the NEXT input chunk (of this tile, or the first of the next tile) is staged while this one is consumed
@@ -224,13 +283,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
         else live_in = false;
       }
       const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
-      const char* lds_in = smem + curi * IN_BYTES;
       auto run_stage = [&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
         constexpr int tap0 = st == 0 ? 0 : STEPS0;
         constexpr int nsteps = st == 0 ? STEPS0 : TAPS - STEPS0;
         // next weight stage: (ic, st + 1), or stage 0 of the next chunk / of the next tile's first chunk
         constexpr int nst_in = (st + 1) % NSTAGE;
+        constexpr int tap0_next = nst_in == 0 ? 0 : STEPS0;
         constexpr int nfrag_next = (nst_in == 0 ? STEPS0 : TAPS - STEPS0) * NB16;
         constexpr int frag0_next = nst_in == 0 ? 0 : STEPS0 * NB16;
         constexpr int w_pieces = WRES ? 0 : (nfrag_next + NW - 1) / NW;
@@ -244,101 +303,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
           }
         }
         const int widx = WRES ? ((ic * NSTAGE + st) & 1) : curw;
-        const char* lds_w = smem + 2 * IN_BYTES + widx * W_BYTES;
+        const int widx_next = WRES ? ((next_wc * NSTAGE + nst_in) & 1) : (curw ^ 1);
         const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
         // input pieces of this stage: IN_PER_WAVE split over the NSTAGE stages of the chunk
         constexpr int IN_PER_ST = (IN_PER_WAVE + NSTAGE - 1) / NSTAGE;
         constexpr int in_q0 = st * IN_PER_ST;
         constexpr int in_pieces = (st + 1 == NSTAGE) ? IN_PER_WAVE - in_q0 : IN_PER_ST;
         constexpr int ndma = in_pieces + w_pieces;
-        constexpr int pps = (ndma + nsteps - 1) / nsteps;      // DMA pieces per k-step
-        const char* wsrc = live_w ? wbase + ((size_t)next_wc * (TAPS * NB16) + frag0_next) * 1024 : zero;
-        const unsigned wmask = live_w ? ~0u : 0u;
+        constexpr int dsteps = nsteps - 1;                     // the last k-step carries the barrier instead
+        constexpr int pps = (ndma + dsteps - 1) / dsteps;      // DMA pieces per k-step (<= 3: one behind each of the
+        static_assert(pps <= 3, "one DMA piece behind each of the first three A fragments of a k-step");
+        const unsigned wfrag = (unsigned)(next_wc * (TAPS * NB16) + frag0_next);
         auto issue_piece = [&](int q) {
           if (q < in_pieces) issue_input(in_q0 + q, next_in, nbuf_in, live_in);
-          else issue_weight(q - in_pieces, wsrc, wmask, nfrag_next, nbuf_w);
+          else issue_weight(q - in_pieces, wfrag, live_w, nfrag_next, nbuf_w);
         };
-
-        {
-          // LDS byte offsets of this stage's buffers, opaque to the optimiser: the fragment reads then keep their
-          // compile-time parts (tap / column-block offsets < 64 KiB) in the instruction's offset field instead of
-          // one v_add per read (the compiler would otherwise specialise the loop per buffer parity)
-          int a_base = (int)lds_address(lds_in) + (p00 << 6), w_base = (int)lds_address(lds_w) + lane * 16;
-          asm volatile("" : "+v"(a_base), "+v"(w_base));
-          const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
-          frag_t fa[2][MB][2], fb[2][CBS];
-          int an[MB][2];                                     // addresses of the NEXT step's A fragments
-          auto a_addrs = [&](int s_next) {
-            const int t = tap0 + s_next;
+        // LDS byte offsets of this stage's and the next stage's buffers, opaque to the optimiser: the fragment reads
+        // then keep their compile-time parts (tap / column-block offsets < 64 KiB) in the instruction's offset field
+        int a_base = (int)lds0 + curi * IN_BYTES + (p00 << 6);
+        int a_next = (int)lds0 + ((st + 1 == NSTAGE) ? (curi ^ 1) : curi) * IN_BYTES + (p00 << 6);
+        int w_base = (int)ldsw0 + widx * W_BYTES + lane * 16;
+        int w_next = (int)ldsw0 + widx_next * W_BYTES + lane * 16;
+        asm volatile("" : "+v"(a_base), "+v"(a_next), "+v"(w_base), "+v"(w_next));
+        static_for<0, nsteps>([&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
+          constexpr bool last = s + 1 == nsteps;
+          constexpr int tn = last ? tap0_next : tap0 + s + 1;  // tap and buffer slot of the k-step after this one
+          constexpr int un = last ? 0 : s + 1;
+          const int ab = last ? a_next : a_base, wb = last ? w_next : w_base;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+          for (int ag = 0; ag < 2 * MB; ++ag) {
+            const int mb = ag >> 1, ps = ag & 1;
 #pragma unroll
-              for (int ps = 0; ps < 2; ++ps) {
-                const int rr = mb + t / 3, col = 4 * ps + (t % 3);
-                const unsigned sw = __builtin_amdgcn_ubfe(rr < 2 ? swz_lo : swz_hi, 2 * ((rr & 1) * 8 + col), 2);
-                an[mb][ps] = a_base + (int)(sw << 4) + (rr * HP + col) * 64;
+            for (int cb = 0; cb < NB16; ++cb) {
+              acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), acc[mb][ps][cb], 0, 0, 0);
+              if (ag == 2 * MB - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + wb + (un * NB16 + cb) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+              } else if (cb == NB16 / 2 - 1 && !last && ag < pps && s * pps + ag < ndma) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(s * pps + ag);
+                __builtin_amdgcn_sched_barrier(0);
               }
-          };
-          auto load_a = [&](frag_t (&a)[MB][2]) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-              for (int ps = 0; ps < 2; ++ps) a[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + an[mb][ps]);
-          };
-          auto load_b = [&](int u, frag_t (&b)[CBS]) {        // sub-step u = s * HN + hh
-#pragma unroll
-            for (int cb = 0; cb < CBS; ++cb)
-              b[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + (u * CBS + cb) * 1024);
-          };
-          a_addrs(0);
-          load_a(fa[0]);
-          load_b(0, fb[0]);
-          if (nsteps > 1) a_addrs(1);
-          static_for<0, nsteps * HN>([&](auto u_c) {
-            {
-              constexpr int u = decltype(u_c)::value, s = u / HN, hh = u % HN;
-              // ---- the LDS reads of the NEXT sub-step first: they have this sub-step's MFMAs to land
-              if (u + 1 < nsteps * HN) load_b(u + 1, fb[(u + 1) & 1]);
-              if (hh == HN - 1 && s + 1 < nsteps) load_a(fa[(s + 1) & 1]);
-#if UNETK_K32_SCHED == 0
-              __builtin_amdgcn_sched_barrier(0);
-#endif
-              // ---- then DMA issue, the addresses of the step after next, and the MFMAs (interleaved by the compiler)
-              if (hh == 0) {
-#pragma unroll
-                for (int q = s * pps; q < (s + 1) * pps && q < ndma; ++q) issue_piece(q);
-              }
-              if (hh == HN - 1 && s + 2 < nsteps) a_addrs(s + 2);
-#pragma unroll
-              for (int cb = 0; cb < CBS; ++cb)
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                  for (int ps = 0; ps < 2; ++ps)
-                    acc[mb][ps][hh * CBS + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[s & 1][mb][ps]), __builtin_bit_cast(bf16x8, fb[u & 1][cb]),
-                        acc[mb][ps][hh * CBS + cb], 0, 0, 0);
-#if UNETK_K32_SCHED == 2
-              {
-                // one LDS read behind each of the first MFMAs: the reads of all eight (phase-locked) waves then
-                // spread over the MFMA time instead of arriving at the LDS port as one burst
-                constexpr int nld = ((u + 1 < nsteps * HN) ? CBS : 0) + ((hh == HN - 1 && s + 1 < nsteps) ? 4 : 0);
-#pragma unroll
-                for (int k = 0; k < nld; ++k) {
-                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * CBS - nld > 0 ? 4 * CBS - nld : 0, 0);
-              }
-#endif
-              // pin the sub-step: without it the scheduler hoists the LDS reads of several sub-steps ahead and the
-              // 128 accumulators + two fragment sets no longer fit 256 registers (spills inside the MFMA loop)
-              __builtin_amdgcn_sched_barrier(0);
             }
-          });
-        }
-        // next stage landed (this wave's DMAs) and every wave is done reading the current buffers
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (ag == 0 && last) {
+              // next stage landed (this wave's DMAs), every wave holds its last fragments of the current buffers
+              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            read_a(mb, ps, tn, ab);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
         curw ^= 1;
       };
       run_stage(std::integral_constant<int, 0>{});

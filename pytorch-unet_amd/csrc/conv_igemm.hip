@@ -27,6 +27,9 @@
 #ifndef UNETK_DB_PIPE
 #define UNETK_DB_PIPE 1      // conv3x3_db_kernel: single fragment set, mid-step chunk barrier (0: round-2 loop)
 #endif
+#ifndef UNETK_DB_PRIO
+#define UNETK_DB_PRIO 0
+#endif
 #ifndef UNETK_DB_DMAPOS
 #define UNETK_DB_DMAPOS 0    // row-block-1 MFMA of a k-step behind which its DMA piece is issued
 #endif
@@ -442,6 +445,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
   }
 
 #if UNETK_DB_PIPE
+#if UNETK_DB_PRIO
+  if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   // ONE fragment register set, each fragment re-read right after the MFMA that used it last; the k-step stream runs
   // on across weight chunks, input chunks and tiles.  The chunk barrier sits in the MIDDLE of a chunk's last k-step
   // (after its row-block-0 MFMAs): every wave then holds that step's fragments in registers, i.e. is done reading the
@@ -507,7 +513,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
           const char* rw = last ? nlds_w : lds_w;
           const int rsub = last ? nsub : sub;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[0][nb], fa[0], fb[nb]);
+          for (int nb = 0; nb < NB; ++nb) {
+            Mma<T>::run(acc[0][nb], fa[0], fb[nb]);
+            if (nb + 1 == -UNETK_DB_DMAPOS && !last) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = st * PPS; q < (st + 1) * PPS && q < NDMA; ++q) issue_piece(q);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (last) {
             // next chunks landed (this wave's DMAs), every wave holds its last fragments of the current buffers
