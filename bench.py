@@ -294,19 +294,20 @@ def main(argv=None):
             torch.cuda.synchronize()
         table = kt.summary()
         # the conv3x3 fprop/dgrad launches of the step by the device kernel that served them; the roofline object is the
-        # DOMINANT kernel's (conv3x3_db_kernel: its rocprofv3 --kernel-trace row must show the same average duration),
-        # the whole family (with the 16x16x32 kernels of the 64-channel n-tiles) rides along as `conv3x3_family`
+        # DOMINANT kernel's (bf16: conv3x3_k32_kernel, the 128-channel n-tiles -- its rocprofv3 --kernel-trace row must
+        # show the same average duration; fp32: conv3x3_db_kernel), the whole family rides along as `conv3x3_family`
         per_kernel = kt.by_device_kernel()
-        n_l, ms, fl, alg_bytes = per_kernel.get('conv3x3_db_kernel', (0, 0.0, 0.0, 0.0))
+        dom = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
+        n_l, ms, fl, alg_bytes = per_kernel.get(dom, (0, 0.0, 0.0, 0.0))
         fam = [sum(v[i] for v in per_kernel.values()) for i in range(3)]
         if ms > 0:
             achieved = fl / (ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[dtype_name]
-            tname = 'bf16' if cfg['amp'] else 'float'
+            what = {'conv3x3_k32_kernel': 'GEMM-N a multiple of 128, v_mfma_f32_16x16x32_bf16',
+                    'conv3x3_k32n64_kernel': 'GEMM-N = 64, v_mfma_f32_16x16x32_bf16',
+                    'conv3x3_db_kernel': 'fp32: every conv3x3 launch, v_mfma_f32_32x32x2_f32'}[dom]
             roofline = {'bound': 'mfma',
-                        'kernel': f'conv3x3_db_kernel<{tname}> (conv3x3 fprop{" + dgrad" if cfg["train"] else ""} '
-                                  'launches of one step with GEMM-N a multiple of 128'
-                                  f'{"" if cfg["amp"] else "; fp32: every conv3x3 launch"})',
+                        'kernel': f'{dom} (conv3x3 fprop{" + dgrad" if cfg["train"] else ""} launches of one step: {what})',
                         'launches_per_step': n_l, 'avg_launch_ms': ms / n_l, 'achieved': achieved, 'peak': peak,
                         'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
                         'algorithmic_bytes_per_launch': alg_bytes / n_l,
@@ -316,14 +317,13 @@ def main(argv=None):
                                             'frac': v[2] / (v[1] * 1e-3) / 1e12 / peak} for k, v in per_kernel.items()},
                             'launches_per_step': fam[0], 'achieved': fam[2] / (fam[1] * 1e-3) / 1e12,
                             'frac': fam[2] / (fam[1] * 1e-3) / 1e12 / peak,
-                            'note': 'conv3x3_k32 = conv3x3_k32n64_kernel / conv3x3_k32_kernel (64-channel n-tiles); the two '
-                                    'fused dgrad + BN-backward-reduce launches are counted with their conv FLOPs only'}}
+                            'note': 'launches with a fused BN-backward reduction are counted with their conv FLOPs only'}}
             if args.config == 'train959' and (hh, ww, B) == (H, W, 16):
                 # counters of THIS command from committed --pmc passes; only quoted for the configuration they were
                 # taken on, with their source
-                tr = committed_profile('*_conv_traffic.json', lambda d: d.get('hbm_bytes_per_launch'))
-                mb = committed_profile('*_mfma_util.json',
-                                       lambda d: d.get('conv3x3_db_kernel', {}).get('mfma_busy_fraction'))
+                tr = committed_profile('*_conv_traffic.json',
+                                       lambda d: d.get('hbm_bytes_per_launch') if d.get('kernel', dom) == dom else None)
+                mb = committed_profile('*_mfma_util.json', lambda d: d.get(dom, {}).get('mfma_busy_fraction'))
                 if tr:
                     roofline['traffic'] = tr['value']
                     roofline['traffic_source'] = tr['source']

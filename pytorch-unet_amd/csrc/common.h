@@ -63,6 +63,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The shipped library takes no tuning input from the environment: every knob is a compile-time constant unless the
+// library is built with -DUNETK_TUNING (A/B builds, scripts/build_variant.sh), where it is read once per process.
+#include <stdlib.h>
+#ifdef UNETK_TUNING
+static inline int unetk_knob(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#define UNETK_KNOB(var, name, dflt) static const int var = unetk_knob(name, dflt)
+#else
+#define UNETK_KNOB(var, name, dflt) constexpr int var = (dflt)
+#endif
+
 static inline int host_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Kernels with more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is a PER-DEVICE

@@ -42,6 +42,9 @@
 #ifndef UNETK_K32_DSTEPS
 #define UNETK_K32_DSTEPS 0   /* 0: 5 with resident weights (5 pieces), 3 otherwise (10 pieces) -- measured best of 3/5 */
 #endif
+#ifndef UNETK_K32_FIRSTC
+#define UNETK_K32_FIRSTC 0
+#endif
 #ifndef UNETK_K32_LDSSTATS
 #define UNETK_K32_LDSSTATS 0
 #endif
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
         else live_in = false;
       }
       const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
-      auto run_stage = [&](auto st_c) {
+      auto run_stage = [&](auto st_c, auto first_c) {
         constexpr int st = decltype(st_c)::value;
+        constexpr bool FIRSTC = decltype(first_c)::value;    // first chunk of a tile: its first k-step starts from C = 0
         constexpr int tap0 = st == 0 ? 0 : STEPS0;
         constexpr int nsteps = st == 0 ? STEPS0 : TAPS - STEPS0;
         // next weight stage: (ic, st + 1), or stage 0 of the next chunk / of the next tile's first chunk
@@ -336,8 +340,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
             const int mb = ag >> 1, ps = ag & 1;
 #pragma unroll
             for (int cb = 0; cb < NB16; ++cb) {
+              const f32x4v c_in = (FIRSTC && st == 0 && s == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
               acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), acc[mb][ps][cb], 0, 0, 0);
+                  __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), c_in, 0, 0, 0);
               if (ag == 2 * MB - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + wb + (un * NB16 + cb) * 1024);
@@ -359,8 +364,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
         });
         curw ^= 1;
       };
-      run_stage(std::integral_constant<int, 0>{});
-      if constexpr (NSTAGE == 2) run_stage(std::integral_constant<int, 1>{});
+#if UNETK_K32_FIRSTC
+      if (ic == 0) run_stage(std::integral_constant<int, 0>{}, std::true_type{});
+      else
+#endif
+        run_stage(std::integral_constant<int, 0>{}, std::false_type{});
+      if constexpr (NSTAGE == 2) run_stage(std::integral_constant<int, 1>{}, std::false_type{});
       curi ^= 1;
     }
 
@@ -401,8 +410,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
           }
       }
     }
+    bool done = false;
+    if constexpr (!AFF) {
+      // Interior tiles (no pixel outside the image): no per-element predicates; the accumulators are rounded ONCE into
+      // packed pairs of horizontally adjacent pixels, the BatchNorm statistics come from the packed values with
+      // v_dot2c_f32_bf16 (sum: y.1, sum of squares: y.y -- exact bf16 products accumulated in fp32, two pixels per
+      // instruction) and a pixel's NB16 adjacent channels are gathered with v_perm into one 16-byte (8-byte) store.
+      if ((y0 + TR <= P.H) && (x0 + 32 <= P.W)) {
+        auto fast = [&](auto stats_c) {
+          constexpr bool ST = decltype(stats_c)::value;
+          const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int yy = y0 + MB * wid + mb;
+            bf16* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy + lane_off;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+              for (int i = 0; i < 4; i += 2) {
+                unsigned pk[NB16];
+#pragma unroll
+                for (int cb = 0; cb < NB16; ++cb) {
+                  const bf16x2 y2 = {(bf16)acc[mb][ps][cb][i], (bf16)acc[mb][ps][cb][i + 1]};
+                  pk[cb] = __builtin_bit_cast(unsigned, y2);
+                  if (!UNETK_K32_FIRSTC) acc[mb][ps][cb][i] = acc[mb][ps][cb][i + 1] = 0.f;
+                  if constexpr (ST && !LDSSTATS) {    // straight into the workgroup-long sums (fp32, as the 64-channel kernel)
+                    tsum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, tsum[cb], false);
+                    tsq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, tsq[cb], false);
+                  } else if constexpr (ST) {
+                    ssum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, ssum[cb], false);
+                    ssq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, ssq[cb], false);
+                  }
+                }
+                typedef __attribute__((ext_vector_type(NB16 / 2))) unsigned uvec;
+                uvec p0, p1;
+#pragma unroll
+                for (int k = 0; k < NB16 / 2; ++k) {
+                  p0[k] = __builtin_amdgcn_perm(pk[2 * k + 1], pk[2 * k], 0x05040100u);
+                  p1[k] = __builtin_amdgcn_perm(pk[2 * k + 1], pk[2 * k], 0x07060302u);
+                }
+                __builtin_nontemporal_store(p0, reinterpret_cast<uvec*>(rowp + (4 * ps + i) * P.ldy));
+                __builtin_nontemporal_store(p1, reinterpret_cast<uvec*>(rowp + (4 * ps + i + 1) * P.ldy));
+                // (fence: the scheduler otherwise rounds the whole tile up front and the allocator spills)
+                __builtin_amdgcn_sched_barrier(0);
+              }
+          }
+        };
+        if (P.stats != nullptr) fast(std::true_type{});
+        else fast(std::false_type{});
+        done = true;
+      }
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+      if (done) break;
       const int yy = y0 + MB * wid + mb;
       bf16* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;   // 64-bit arithmetic once per row (wave-uniform)
 #pragma unroll
@@ -419,17 +480,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
               } else {
                 const float f = to_f32(from_f32<bf16>(acc[mb][ps][cb][i]));   // statistics of the value as stored
                 v[cb] = f;
-                if (!(UNETK_K32_ABL & 1)) {
-                  ssum[cb] += f;
-                  ssq[cb] += f * f;
-                }
+                ssum[cb] += f;
+                ssq[cb] += f * f;
               }
             }
-            if (!(UNETK_K32_ABL & 2)) store_adjacent<NB16>(rowp + ri * P.ldy + lane_off, v);
-            else asm volatile("" ::"v"(v[0]), "v"(v[NB16 - 1]));
+            store_adjacent<NB16>(rowp + ri * P.ldy + lane_off, v);
           }
+          if (!UNETK_K32_FIRSTC) {
 #pragma unroll
-          for (int cb = 0; cb < NB16; ++cb) acc[mb][ps][cb][i] = 0.f;
+            for (int cb = 0; cb < NB16; ++cb) acc[mb][ps][cb][i] = 0.f;
+          }
         }
     }
 #pragma unroll
@@ -926,7 +986,10 @@ template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t
       if (cost < best * 0.999) { best = cost; tpb = t; }
     }
   }
-  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  {
+    UNETK_KNOB(tpb_force, "UNETK_CONV_TPB", 0);
+    if (tpb_force > 0) tpb = tpb_force;
+  }
   Q.tpb = tpb;
   const long nblk = (ntiles + tpb - 1) / tpb;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
@@ -961,7 +1024,10 @@ template <int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hip
       if (cost < best * 0.999) { best = cost; tpb = t; }
     }
   }
-  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  {
+    UNETK_KNOB(tpb_force, "UNETK_CONV_TPB", 0);
+    if (tpb_force > 0) tpb = tpb_force;
+  }
   Q.tpb = tpb;
   Q.dbg = 0;
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
@@ -985,7 +1051,7 @@ int unetk_internal_conv3x3_k32(const void* params, void* stream) {
     return aff ? launch_k32<8, true, false>(P, s) : launch_k32<8, false, false>(P, s);
   }
   const bool wres = P.Cin <= 64;                            // <= 2 weight stages: resident in the two buffers
-  static const int nopipe = getenv("UNETK_K32_NOPIPE") ? atoi(getenv("UNETK_K32_NOPIPE")) : 0;
+  const bool nopipe = conv3_k32_nopipe();
   if (!aff && P.Cout == 64 && !nopipe) {
     if (bnr) {                                              // the z fetch needs a stage of its own behind the first
       if (P.Cin < 64) return UNETK_ERR_UNFUSED;

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const floa
 }
 
 int first_nsplit(int ntiles, int col_tiles) {
-  static const int slots = getenv("UNETK_FIRST_SPLIT") ? atoi(getenv("UNETK_FIRST_SPLIT")) : 1024;   // four 256-thread workgroups per CU (35 KiB LDS each): 0.378 -> 0.351 ms
+  UNETK_KNOB(slots, "UNETK_FIRST_SPLIT", 1024);   // four 256-thread workgroups per CU (35 KiB LDS each): 0.378 -> 0.351 ms
   int ns = slots / col_tiles;
   if (ns < 1) ns = 1;
   if (ns > ntiles) ns = ntiles;

@@ -772,9 +772,15 @@ int launch_db(const ConvParams& P, hipStream_t s) {
       if (cost < best * 0.999) { best = cost; tpb = t; }
     }
   }
-  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  {
+    UNETK_KNOB(tpb_force, "UNETK_CONV_TPB", 0);
+    if (tpb_force > 0) tpb = tpb_force;
+  }
   Q.tpb = tpb;
-  Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
+  {
+    UNETK_KNOB(dbg, "UNETK_CONV_DBG", 0);
+    Q.dbg = dbg;
+  }
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
   hipLaunchKernelGGL((conv3x3_db_kernel<T, NB, KS, NW, MB, KI, AFF>), dim3((unsigned)nblk), dim3(64 * NW), lds, s, Q);
@@ -1067,9 +1073,15 @@ template <typename T, int MODE, int NW = 8, int KS = 4> int launch_pw(const Conv
       if (cost < best * 0.999) { best = cost; tpb = t; }
     }
   }
-  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  {
+    UNETK_KNOB(tpb_force, "UNETK_CONV_TPB", 0);
+    if (tpb_force > 0) tpb = tpb_force;
+  }
   Q.tpb = tpb;
-  Q.dbg = getenv("UNETK_CONV_DBG") ? atoi(getenv("UNETK_CONV_DBG")) : 0;
+  {
+    UNETK_KNOB(dbg, "UNETK_CONV_DBG", 0);
+    Q.dbg = dbg;
+  }
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
   Q.nblk = (int)nblk;
@@ -1096,7 +1108,10 @@ template <typename T, int NB, int MODE> int launch(const ConvParams& P, hipStrea
   const int niter = (P.Cin / (2 * G::KS * ElemTraits<T>::E)) * G::OUTER;
   int tpb = (12 + niter - 1) / niter;
   while (tpb > 1 && ((ntiles + tpb - 1) / tpb) * P.n_tiles < 2048) --tpb;
-  if (const char* e = getenv("UNETK_CONV_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;
+  {
+    UNETK_KNOB(tpb_force, "UNETK_CONV_TPB", 0);
+    if (tpb_force > 0) tpb = tpb_force;
+  }
   Q.tpb = tpb;
   const long nblk = ((ntiles + tpb - 1) / tpb) * P.n_tiles;
   if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
@@ -1133,7 +1148,7 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)
       // GEMM-K up to 1024: 4-wave workgroups, two per CU (measured at the four decoder levels: forward 0.48 -> 0.41,
       // 0.35 -> 0.31, 0.23 -> 0.20, 0.22 -> 0.21 ms; dgrad 0.42 -> 0.40, 0.30 -> 0.29 ms; K = 2048 dgrad 0.21 -> 0.22)
-      static const int small = getenv("UNETK_PW_SMALL") ? atoi(getenv("UNETK_PW_SMALL")) : 1024;
+      UNETK_KNOB(small, "UNETK_PW_SMALL", 1024);
       if (dtype == UNETK_BF16 && P.Cin * (MODE == 2 ? 4 : 1) <= small) return launch_pw<bf16, MODE, 4, 2>(P, s);
       if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
@@ -1227,7 +1242,7 @@ int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void*
 int unetk_conv3x3_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype) {
   // mirrors dispatch<0> / unetk_internal_conv3x3_k32: GEMM-N = c_in, GEMM-K = c_out
   if (dtype != UNETK_BF16 || c_in <= 0 || c_out < 64 || c_out % 32 != 0) return 0;
-  return conv3_use_k32(1, c_in) && conv3_k32_nb16(c_in) == 4 && c_in == 64 && !getenv("UNETK_K32_NOPIPE");
+  return conv3_use_k32(1, c_in) && conv3_k32_nb16(c_in) == 4 && c_in == 64 && !conv3_k32_nopipe();
 }
 
 int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,

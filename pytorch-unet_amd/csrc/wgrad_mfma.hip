@@ -1022,7 +1022,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     return UNETK_OK;
   }
   if ((int64_t)h * w * (ldx > lddy ? ldx : lddy) * 2 >= (int64_t)1 << 32) return UNETK_ERR_SHAPE;   // 32-bit DMA offsets
-  static const int wide = getenv("UNETK_WGRAD_WIDE") ? atoi(getenv("UNETK_WGRAD_WIDE")) : 1;   // 0: A/B against 64x64 tiles
+  UNETK_KNOB(wide, "UNETK_WGRAD_WIDE", 1);   // 0: A/B against 64x64 tiles
   if (c_out % 128 == 0 && wide) {
     Wgrad3Params P{};
     P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
@@ -1030,7 +1030,10 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.tiles_x = host_cdiv(w, 8); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
     P.row_tiles = c_in / 64; P.col_tiles = c_out / 128;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
-    P.dbg = getenv("UNETK_WGRAD_DBG") ? atoi(getenv("UNETK_WGRAD_DBG")) : 0;
+    {
+      UNETK_KNOB(dbg, "UNETK_WGRAD_DBG", 0);
+      P.dbg = dbg;
+    }
     const size_t lds = 2 * W4_BUF;
     UNETK_ALLOW_LDS((wgrad4_bf16_kernel), lds);
     hipLaunchKernelGGL(wgrad4_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
@@ -1046,7 +1049,10 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
   P.tiles_x = host_cdiv(w, 16); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
   P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
-  P.dbg = getenv("UNETK_WGRAD_DBG") ? atoi(getenv("UNETK_WGRAD_DBG")) : 0;
+  {
+    UNETK_KNOB(dbg, "UNETK_WGRAD_DBG", 0);
+    P.dbg = dbg;
+  }
   const size_t lds = 2 * W3_BUF;
   UNETK_ALLOW_LDS((wgrad3_bf16_kernel), lds);
   hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
@@ -1088,7 +1094,7 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
-  static const int gen2 = getenv("UNETK_WGRADT_GEN2") ? atoi(getenv("UNETK_WGRADT_GEN2")) : 1;   // 0: A/B runs
+  UNETK_KNOB(gen2, "UNETK_WGRADT_GEN2", 1);   // 0: A/B runs
   if (c_in % 128 == 0 && gen2) {
     if ((int64_t)hs * ws * lddy * 2 >= (int64_t)1 << 32 || (int64_t)h * w * ldx * 2 >= (int64_t)1 << 32)
       return UNETK_ERR_SHAPE;                                  // 32-bit DMA offsets inside an image

@@ -127,14 +127,18 @@ class KernelTimer:
 
     @staticmethod
     def _device_kernel(name, a):
-        """Which conv3x3 kernel serves a launch (csrc/conv_config.h: conv3_use_k32): the 16x16x32 kernels take the bf16
-        launches whose GEMM-N is not a multiple of 128, conv3x3_db_kernel everything else."""
+        """Which conv3x3 kernel serves a launch (csrc/conv_config.h: conv3_use_k32, conv3_k32_nb16): every bf16 launch
+        runs on v_mfma_f32_16x16x32_bf16 -- conv3x3_k32_kernel (128-channel n-tiles) when GEMM-N is a multiple of 128,
+        else conv3x3_k32n64_kernel (64-channel n-tile, epilogue under the next tile; the inference instantiations of that
+        n-tile are conv3x3_k32_kernel<4>); fp32 runs conv3x3_db_kernel (v_mfma_f32_32x32x2_f32)."""
         pos = {'unetk_conv3x3_fprop': (12, 13), 'unetk_conv3x3_dgrad_sums': (11, 13), 'unetk_conv3x3_dgrad': (10, 12),
                'unetk_conv3x3_dgrad_bn_reduce': (17, 19), 'unetk_conv3x3_fprop_bn_relu': (15, 16)}.get(name)
         if pos is None:
             return None
         n_gemm, dtype = a[pos[0]], a[pos[1]]
-        return 'conv3x3_k32' if (dtype == BF16 and n_gemm % 128 != 0) else 'conv3x3_db_kernel'
+        if dtype != BF16:
+            return 'conv3x3_db_kernel'
+        return 'conv3x3_k32_kernel' if n_gemm % 128 == 0 else 'conv3x3_k32n64_kernel'
 
     @staticmethod
     def _conv_bytes(name, a):

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/pytorch-unet_amd/csrc
 OBJ=/tmp/unetk_variant_$NAME
 mkdir -p $OBJ $ROOT/exp
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -DUNETK_TUNING -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result"
 pids=()
 for f in $SRC/*.hip; do
   b=$(basename $f .hip)
