@@ -36,11 +36,8 @@
 #ifndef UNETK_K32_ABL
 #define UNETK_K32_ABL 0      // perf ablations only: 1 no statistics arithmetic, 2 no stores
 #endif
-#ifndef UNETK_K32_STAMP
-#define UNETK_K32_STAMP 0    // diagnostic build: s_memtime stamps around the phases of conv3x3_k32n64_kernel
-#endif
 #ifndef UNETK_K32_DSTEPS
-#define UNETK_K32_DSTEPS 0   /* 0: 5 with resident weights (5 pieces), 3 otherwise (10 pieces) -- measured best of 3/5 */
+#define UNETK_K32_DSTEPS 0   /* k-steps of a tile's first stage that carry its DMA pieces (0: 4) */
 #endif
 #ifndef UNETK_K32_FIRSTC
 #define UNETK_K32_FIRSTC 0
@@ -578,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   // for the DMA only -- the stores complete under the next stage instead of on the barrier.
   // (stages without pending stores spread the pieces over all nine k-steps: an LDS-DMA instruction holds its wave for
   // 60-185 cycles, and in a burst all eight phase-locked waves stall together while the matrix pipe drains)
-  constexpr int DSTEPS = UNETK_K32_DSTEPS ? UNETK_K32_DSTEPS : (WRES ? 5 : 3);
+  constexpr int DSTEPS = UNETK_K32_DSTEPS ? UNETK_K32_DSTEPS : 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -592,7 +589,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 
   const int nin = P.Cin / 32;
   const char* wbase = reinterpret_cast<const char*>(P.wpk);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page_k32);
 
   const int pi = (c16 & 3) + ((c16 >> 2) == 1 ? 16 : (c16 >> 2) == 2 ? 24 : (c16 >> 2) == 3 ? 8 : 0);
   const int p00 = (MB * wid) * HP + pi;
@@ -606,12 +602,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       else swz_hi |= v << (2 * ((rr - 2) * 8 + col));
     }
 
+  // LDS-DMA through buffer descriptors, see conv3x3_k32_kernel: out-of-range lanes (~0u) are zero-filled
   unsigned dma_off[IN_PER_WAVE];
-  const char* ximg = nullptr;
+  u32x4 xdesc = {0u, 0u, 0u, 0x00020000u};
+  const unsigned img_bytes = (unsigned)(((size_t)P.H * P.W * P.ldx - P.xoff) * 2);
   auto setup_stage = [&](int tile) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
-    ximg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+    const unsigned long long xa =
+        (unsigned long long)(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+    xdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)xa);
+    xdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
+    xdesc[2] = img_bytes;
 #pragma unroll
     for (int f = 0; f < IN_PER_WAVE; ++f) {
       const int fi = min(f * NW + wid, IN_INSTR - 1);
@@ -625,18 +627,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       dma_off[f] = off;
     }
   };
+  u32x4 wdesc;
+  {
+    const unsigned long long wa = (unsigned long long)wbase;
+    wdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)wa);
+    wdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(wa >> 32) & 0xffffu);
+    wdesc[2] = (unsigned)nin * W_BYTES;
+    wdesc[3] = 0x00020000u;
+  }
+  const unsigned wlane = lane * 16;
   auto issue_input = [&](int q, int in_chunk, unsigned buf, bool live) {
     const int fi = min(q * NW + wid, IN_INSTR - 1);
-    const bool ok = live && dma_off[q] != ~0u;
-    const char* src = (ok ? ximg : zero) + (ok ? dma_off[q] + (unsigned)in_chunk * 64u : 0u);
-    glds16_hidden(src, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    u32x4 d = xdesc;
+    d[2] = live ? d[2] : 0u;
+    bufdma16(dma_off[q], d, (unsigned)in_chunk * 64u, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
-  // branch-free: `live` is wave-uniform and a ?: over whole addresses becomes an s_cbranch, which ends the k-step's
-  // basic block (full lgkmcnt(0) wait, MFMA issue stalls) -- the base is selected by the caller once per stage and the
-  // lane offset is masked instead
-  auto issue_weight = [&](int q, const char* src_base, unsigned live_mask, unsigned buf) {
+  auto issue_weight = [&](int q, unsigned frag_base, bool live, unsigned buf) {
     const int fi = min(q * NW + wid, NFRAG - 1);
-    glds16_hidden(src_base + ((unsigned)(fi * 1024 + lane * 16) & live_mask), __builtin_amdgcn_readfirstlane(buf + fi * 1024));
+    u32x4 d = wdesc;
+    d[2] = live ? d[2] : 0u;
+    bufdma16(wlane, d, (frag_base + fi) * 1024u, __builtin_amdgcn_readfirstlane(buf + fi * 1024));
   };
 
   f32x4v acc[MB][2][NB16];
@@ -686,11 +696,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 
   // statistics of the pending tile, group g = (mb, ps): 4 channels x 4 pixels = 8 packed registers, 16 instructions.
   // (pixels outside the image were zeroed when the tile was packed; with nothing pending pk is all zero)
-  auto emit_stats = [&](int g) {
+  auto emit_stats = [&](int g, int cb0 = 0, int cb1 = NB16) {
     const int mb = g >> 1, ps = g & 1;
     const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
 #pragma unroll
-    for (int cb = 0; cb < NB16; ++cb)
+    for (int cb = cb0; cb < cb1; ++cb)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const bf16x2 y2 = __builtin_bit_cast(bf16x2, pk[mb][ps][cb][e]);
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
     for (int st = 0; st < 2; ++st)
       if (st < nst)
-        for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, wbase + (size_t)st * W_BYTES, ~0u, ldsw0 + st * W_BYTES);
+        for (int q = 0; q * NW < NFRAG; ++q) issue_weight(q, (unsigned)(st * NFRAG), true, ldsw0 + st * W_BYTES);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int curi = 0, curw = 0;
@@ -743,111 +753,113 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     }
   };
 
-  unsigned long long ph[5] = {0, 0, 0, 0, 0};                // stamps: prologue reads, MFMA steps, wait, barrier, hand-over
+  // ONE fragment register set (4 A + 4 B fragments), each re-read right after the MFMA that used it last; the k-step
+  // stream runs on across stages and tiles, and the stage barrier sits inside the stage's last k-step behind the MFMAs
+  // of its first A fragment (see conv3x3_k32_kernel).  What else a k-step carries -- DMA pieces, the previous tile's
+  // statistics and stores -- goes into the three slots behind the MFMA groups of A fragments 0..2.
+  const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
+  frag_t fa[MB][2], fb[NB16];
+  auto read_a = [&](int mb, int ps, int t, int a_base) {
+    const int rr = mb + t / 3, col = 4 * ps + (t % 3);
+    int addr;      // asm volatile: as plain arithmetic the 28 swizzle terms are hoisted out of the loop and spilled
+    asm volatile("v_bfe_u32 %0, %1, %2, 2\n\tv_lshl_add_u32 %0, %0, 4, %3"
+                 : "=&v"(addr)
+                 : "v"(rr < 2 ? swz_lo : swz_hi), "n"(2 * ((rr & 1) * 8 + col)), "v"(a_base));
+    fa[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + addr + (rr * HP + col) * 64);
+  };
+  {
+    const int a_base = (int)lds0 + (p00 << 6), w_base = (int)ldsw0 + lane * 16;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) read_a(mb, ps, 0, a_base);
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + cb * 1024);
+  }
+
   auto run_stage = [&](auto first_c, auto fetch_c, int tile, int ic) {
     constexpr bool FIRST = decltype(first_c)::value;         // first chunk of a tile: C = 0, and the pending stores
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    if (UNETK_K32_STAMP) t0 = __builtin_amdgcn_s_memtime();
     // BNR: the tile's last stage (never the first: the host sends Cin < 64 elsewhere) starts with the z fetch, which
-    // lands under its MFMAs (vmcnt(0) at its end).  A stage of its own in the code -- not a run-time test -- so that the
-    // z registers are defined on every path to the hand-over and dead before it.
-    if constexpr (decltype(fetch_c)::value && !(UNETK_K32_ABL & 16)) fetch_z(tile);
+    // lands under its MFMAs (vmcnt(0) at its barrier).  A stage of its own in the code -- not a run-time test -- so that
+    // the z registers are defined on every path to the hand-over and dead before it.
+    if constexpr (decltype(fetch_c)::value) fetch_z(tile);
     int next_in = ic + 1;
-    bool live_in = !(UNETK_K32_ABL & 4);
+    bool live_in = true;
     if (ic + 1 == nin) {
       next_in = 0;
       if (tile + 1 < tile_end) setup_stage(tile + 1);
       else live_in = false;
     }
     int next_wc = ic + 1;
-    bool live_w = !(UNETK_K32_ABL & 4);
+    bool live_w = true;
     if (ic + 1 == nin) {
       next_wc = 0;
       live_w = tile + 1 < tile_end;
     }
     const unsigned nbuf_in = lds0 + (curi ^ 1) * IN_BYTES;
     const unsigned nbuf_w = ldsw0 + (curw ^ 1) * W_BYTES;
-    const char* wsrc = live_w ? wbase + (size_t)next_wc * W_BYTES : zero;
-    const unsigned wmask = live_w ? ~0u : 0u;
+    const unsigned wfrag = (unsigned)(next_wc * NFRAG);
     const int widx = WRES ? (ic & 1) : curw;
-    int a_base = (int)(lds0 + curi * IN_BYTES) + (p00 << 6), w_base = (int)(ldsw0 + widx * W_BYTES) + lane * 16;
-    asm volatile("" : "+v"(a_base), "+v"(w_base));           // keep tap / fragment offsets in the ds_read offset field
-    const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
-    frag_t fa[2][MB][2], fb[2][NB16];
-    int an[MB][2];
-    auto a_addrs = [&](int t) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-          const int rr = mb + t / 3, col = 4 * ps + (t % 3);
-          const unsigned sw = __builtin_amdgcn_ubfe(rr < 2 ? swz_lo : swz_hi, 2 * ((rr & 1) * 8 + col), 2);
-          an[mb][ps] = a_base + (int)(sw << 4) + (rr * HP + col) * 64;
-        }
-    };
-    auto load_ab = [&](int t, frag_t (&a)[MB][2], frag_t (&b)[NB16]) {
-#pragma unroll
-      for (int cb = 0; cb < NB16; ++cb) b[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + w_base + (t * NB16 + cb) * 1024);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) a[mb][ps] = *reinterpret_cast<const AS3 frag_t*>(lds3 + an[mb][ps]);
-    };
-    a_addrs(0);
-    load_ab(0, fa[0], fb[0]);
-    a_addrs(1);
-    if (UNETK_K32_STAMP) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      t1 = __builtin_amdgcn_s_memtime();
-    }
+    const int widx_next = WRES ? (next_wc & 1) : (curw ^ 1);
+    int a_base = (int)(lds0 + curi * IN_BYTES) + (p00 << 6), a_next = (int)(lds0 + (curi ^ 1) * IN_BYTES) + (p00 << 6);
+    int w_base = (int)(ldsw0 + widx * W_BYTES) + lane * 16, w_next = (int)(ldsw0 + widx_next * W_BYTES) + lane * 16;
+    asm volatile("" : "+v"(a_base), "+v"(a_next), "+v"(w_base), "+v"(w_next));   // keep tap / fragment offsets immediate
+    const bool keep_stores = FIRST && st_all16;
+    // slots (k-step t, A fragment ag) with t < 8, ag < 3: 24 per stage.  A first stage issues its DMA pieces in the
+    // first DSTEPS k-steps and the 16 pending stores behind them (so that the stores are the youngest vector-memory
+    // operations and the barrier's vmcnt(16) waits for the DMA only); other stages spread the pieces over all 24 slots.
+    constexpr int DS = FIRST ? DSTEPS : 8;
+    constexpr int DSLOTS = 3 * DS, SSLOTS = 24 - 3 * DSTEPS;
     static_for<0, TAPS>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
-      // the LDS reads of the NEXT k-step first: they have this step's 16 MFMAs to land
-      if (t + 1 < TAPS) load_ab(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      constexpr int DS = FIRST ? DSTEPS : TAPS, PPS = (NDMA + DS - 1) / DS;
+      constexpr bool last = t + 1 == TAPS;
+      constexpr int tn = last ? 0 : t + 1;
+      const int ab = last ? a_next : a_base, wb = last ? w_next : w_base;
 #pragma unroll
-      for (int q = t * PPS; q < (t + 1) * PPS && q < NDMA; ++q) {
-        if (q < IN_PER_WAVE) issue_input(q, next_in, nbuf_in, live_in);
-        else issue_weight(q - IN_PER_WAVE, wsrc, wmask, nbuf_w);
-      }
-      if (t + 2 < TAPS) a_addrs(t + 2);
-      if constexpr (FIRST && STATS) {
-        if (t < 4 && !(UNETK_K32_ABL & 1)) emit_stats(t);     // before the group's stores: pk is read-only, any order
-      }
-      if constexpr (FIRST) {
-        // 16 stores of the previous tile: 3, 3, 3, 3, 2, 2 over the k-steps behind the DMA
-        constexpr int SS = TAPS - DSTEPS;                    // steps that carry stores
-        constexpr int k0 = t < DSTEPS ? 16 : (16 * (t - DSTEPS)) / SS;
-        constexpr int k1 = t < DSTEPS ? 16 : (16 * (t + 1 - DSTEPS)) / SS;
+      for (int ag = 0; ag < 2 * MB; ++ag) {
+        const int mb = ag >> 1, ps = ag & 1;
 #pragma unroll
-        for (int k = k0; k < k1 && k < 16; ++k) emit_store(k);
-      }
-#pragma unroll
-      for (int cb = 0; cb < NB16; ++cb)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int ps = 0; ps < 2; ++ps) {
-            const f32x4v c_in = (FIRST && t == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
-            acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, fa[t & 1][mb][ps]), __builtin_bit_cast(bf16x8, fb[t & 1][cb]), c_in, 0, 0, 0);
+        for (int cb = 0; cb < NB16; ++cb) {
+          const f32x4v c_in = (FIRST && t == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
+          acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), c_in, 0, 0, 0);
+          if (ag == 2 * MB - 1 && !(UNETK_K32_ABL & 32)) {
+            __builtin_amdgcn_sched_barrier(0);
+            fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + wb + (tn * NB16 + cb) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
           }
-      __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ag == 0 && last) {
+          // next stage landed (this wave's DMAs; the 16 stores behind them may stay in flight -- but only when each of
+          // them really was a vector-memory operation with a lane to write), every wave holds its last fragments
+          if (keep_stores) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (!(UNETK_K32_ABL & 64)) read_a(mb, ps, tn, ab);
+        if (!last && ag < 3) {
+          const int sl = 3 * t + ag;
+          // DMA pieces: piece q goes into slot q * DSLOTS / NDMA
+#pragma unroll
+          for (int q = 0; q < NDMA; ++q)
+            if ((q * DSLOTS) / NDMA == sl) {
+              if (q < IN_PER_WAVE) issue_input(q, next_in, nbuf_in, live_in);
+              else issue_weight(q - IN_PER_WAVE, wfrag, live_w, nbuf_w);
+            }
+          if constexpr (FIRST && STATS) {
+            // statistics of the previous tile, group t: channels {0,1}, {2}, {3} behind A fragments 0, 1, 2
+            if (t < 4 && !(UNETK_K32_ABL & 1)) emit_stats(t, ag == 0 ? 0 : ag + 1, ag + 2);
+          }
+          if constexpr (FIRST) {
+            // the 16 stores of the previous tile: store k goes into slot 3 * DSTEPS + k * SSLOTS / 16
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+              if (3 * DSTEPS + (k * SSLOTS) / 16 == sl) emit_store(k);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
-    // next stage landed (this wave's DMAs) and every wave is done reading the current buffers.  The 16 stores may stay
-    // in flight -- but only when each of them really was a vector-memory operation with a lane to write (a store whose
-    // EXEC mask is empty must not be relied on to count)
-    if (UNETK_K32_STAMP) {
-      t2 = __builtin_amdgcn_s_memtime();
-      if (FIRST && st_all16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      t3 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_barrier" ::: "memory");
-      t4 = __builtin_amdgcn_s_memtime();
-      ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
-    } else if (FIRST && st_all16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     curw ^= 1;
     curi ^= 1;
   };
@@ -862,8 +874,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     }
 
     // ---- hand the tile over: round, statistics, remember where it goes.  Its stores ride under the next tile.
-    unsigned long long th = 0;
-    if (UNETK_K32_STAMP) th = __builtin_amdgcn_s_memtime();
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
     const bf16* yimg = reinterpret_cast<const bf16*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
@@ -918,16 +928,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
         for (int cb = 0; cb < NB16; ++cb) { pk[mb][ps][cb][0] = rnd[cb][0]; pk[mb][ps][cb][1] = rnd[cb][1]; }
       }
-    if (UNETK_K32_STAMP) {
-      asm volatile("" ::"v"(pk[1][1][NB16 - 1][1]));
-      ph[4] += __builtin_amdgcn_s_memtime() - th;
-    }
-  }
-  if (UNETK_K32_STAMP && P.stamps != nullptr && lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 5; ++q) P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + q] = ph[q];
-    P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + 5] = tile_end - tile_begin;
-    P.stamps[((size_t)blockIdx.x * NW + wid) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
   }
   // the last tile's statistics and stores
   if constexpr (STATS) {
@@ -993,10 +993,6 @@ template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t
   Q.tpb = tpb;
   const long nblk = (ntiles + tpb - 1) / tpb;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  if (UNETK_K32_STAMP) {   // diagnostic build: UNETK_STAMP_PTR = device buffer of nblk * 8 waves * 8 u64
-    const char* e = getenv("UNETK_STAMP_PTR");
-    Q.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
-  }
   hipLaunchKernelGGL((conv3x3_k32n64_kernel<WRES, EPI>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
