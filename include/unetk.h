@@ -276,7 +276,12 @@ int unetk_eval_dice(const void* logits, int ld, const int64_t* mask, int n, int6
  * process ends); the call itself performs no hipMalloc/hipFree.  n * n_classes > UNETK_EVAL_NOALLOC_MAX_GROUPS
  * returns UNETK_ERR_TOO_LARGE (use unetk_eval_dice with a workspace).  All calls on one GPU share that array: calls
  * on the SAME stream are ordered and safe; calls that overlap on one GPU (different streams, or threads launching
- * concurrently) race on the counters and must be serialised by the caller. */
+ * concurrently) race on the counters and must be serialised by the caller.
+ * Preconditions: the device that owns `logits` (and `stream`) must be the CURRENT device of the calling thread -- each
+ * GPU has its own copy of the array at its own address; a mismatch (or a host pointer) returns UNETK_ERR_ARG.  The
+ * first call on a device looks the array's address up (hipGetSymbolAddress: a lazy code-object load that may allocate
+ * and is not allowed under stream capture): make ONE ordinary, un-captured call per device (or per process and
+ * device) before capturing or entering a no-allocation region; every later call allocates nothing. */
 #define UNETK_EVAL_NOALLOC_MAX_GROUPS 4096
 int unetk_eval_dice_noalloc(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes,
                             int first_class, float eps, float* dice_out, int dtype, void* stream);

@@ -423,11 +423,27 @@ __device__ __align__(256) unsigned long long g_eval_scratch[UNETK_EVAL_NOALLOC_M
 constexpr int kMaxDevices = 64;
 unsigned long long* g_eval_scratch_ptr[kMaxDevices];     // per device; 0 = not asked yet
 
-unsigned long long* eval_scratch_for_current_device() {
+// The scratch of the device that OWNS `logits` -- which must also be the current device (the stream belongs to it and
+// the kernels are launched on it): a caller whose current device differs would otherwise get another GPU's symbol
+// address.  Returns nullptr with *err set: UNETK_ERR_ARG for the device mismatch, UNETK_ERR_LAUNCH for a HIP failure.
+unsigned long long* eval_scratch_for(const void* logits, int* err) {
   int dev = -1;
+  *err = UNETK_ERR_LAUNCH;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, logits) != hipSuccess) {
+    (void)hipGetLastError();
+    *err = UNETK_ERR_ARG;
+    return nullptr;
+  }
+  if (attr.type != hipMemoryTypeDevice || attr.device != dev) {
+    *err = UNETK_ERR_ARG;
+    return nullptr;
+  }
   unsigned long long* p = __atomic_load_n(&g_eval_scratch_ptr[dev], __ATOMIC_ACQUIRE);
   if (p) return p;
+  // first call on this device: the symbol lookup loads the code object (it may allocate, and is refused under stream
+  // capture) -- include/unetk.h asks for one un-captured warm-up call per device
   void* addr = nullptr;
   if (hipGetSymbolAddress(&addr, HIP_SYMBOL(g_eval_scratch)) != hipSuccess || !addr) return nullptr;
   p = static_cast<unsigned long long*>(addr);
@@ -548,8 +564,9 @@ int unetk_eval_dice_noalloc(const void* logits, int ld, const int64_t* mask, int
                             int first_class, float eps, float* dice_out, int dtype, void* stream) {
   if (int e = eval_dice_check(logits, ld, mask, n, hw, n_classes, first_class, dice_out, dtype)) return e;
   if ((long)n * n_classes > UNETK_EVAL_NOALLOC_MAX_GROUPS) return UNETK_ERR_TOO_LARGE;
-  unsigned long long* counts = eval_scratch_for_current_device();
-  if (!counts) return UNETK_ERR_LAUNCH;
+  int err = UNETK_OK;
+  unsigned long long* counts = eval_scratch_for(logits, &err);
+  if (!counts) return err;
   return eval_dice_launch(logits, ld, mask, n, hw, n_classes, first_class, eps, counts, dice_out, dtype,
                           (hipStream_t)stream);
 }

@@ -32,15 +32,17 @@ class ClipRMSprop(torch.optim.Optimizer):
         super().zero_grad(set_to_none=set_to_none)
 
     # ---- checkpoint / resume in torch.optim.RMSprop's own format (train.py saves only the model's state_dict, but a
-    # user who checkpoints the optimizer can move between the two): per-parameter 'step', 'square_avg',
-    # 'momentum_buffer', keyed by the parameter's index in the group
+    # user who checkpoints the optimizer can move between the two, in BOTH directions): per-parameter 'step',
+    # 'square_avg', 'momentum_buffer', keyed by the parameter's index in net.parameters() order -- the order a stock
+    # optimizer built from `net.parameters()` maps indices by (it checks group sizes only, not shapes)
     def state_dict(self):
         g = self.param_groups[0]
+        order = list(self.fg.module_order)
         group = {k: v for k, v in g.items() if k != 'params'}
-        group.update(centered=False, params=list(range(len(self.fg.params))))
+        group.update(centered=False, params=list(range(len(order))), unetk_order='module')
         state = {}
         if self._steps > 0:
-            for i, p in enumerate(self.fg.params):
+            for i, p in enumerate(order):
                 off, n = self.fg.offsets[id(p)], p.numel()
                 st = {'step': torch.tensor(float(self._steps)),
                       'square_avg': self.square_avg[off:off + n].view(p.shape).clone()}
@@ -62,9 +64,6 @@ class ClipRMSprop(torch.optim.Optimizer):
         self.square_avg.zero_()
         self.momentum_buf.zero_()
         steps = 0
-        # the parameters are listed in gradient-completion order here and in module order in a stock optimizer: match
-        # by position only when the saved indices came from this class (same order) -- torch's checkpoints are matched
-        # through `param_names` when present, else by position in net.parameters() order
         order = self._saved_order(groups[0])
         for i, st in state_dict['state'].items():
             p = order[int(i)]
@@ -78,7 +77,10 @@ class ClipRMSprop(torch.optim.Optimizer):
         self._steps = steps
 
     def _saved_order(self, group):
-        if 'max_norm' in group:          # written by this class: gradient-completion order
+        """Checkpoints of a stock torch.optim.RMSprop and of this class (marker `unetk_order`) number the parameters in
+        net.parameters() order; files this class wrote before it carried the marker (round 2: 'max_norm' present, no
+        marker) used gradient-completion order and still load."""
+        if 'max_norm' in group and group.get('unetk_order') != 'module':
             return self.fg.params
         return list(self.fg.module_order)
 

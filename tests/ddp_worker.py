@@ -2,9 +2,10 @@
 
     python tests/ddp_worker.py <rank> <world> <port> <out dir>
 
-Runs ONE training step (Trainer.step's sequence) of the real whole-net backward on this rank's own images -- the gradient buckets go out over
-`gloo` (on CUDA tensors) while the backward is still running -- and writes the flat gradient buffer, the loss and
-two updated parameters."""
+Runs ONE training step (Trainer.step's sequence) of the real whole-net backward on this rank's own images -- the
+gradient buckets go out over `gloo` while the backward is still running (FlatGrads._launch stages each bucket through
+the host for gloo; RCCL reduces the device buffer in place) -- and writes the flat gradient buffer, the loss and two
+updated parameters."""
 import os
 import sys
 

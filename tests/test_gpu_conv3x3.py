@@ -143,15 +143,20 @@ def test_conv3x3_dgrad_with_bn_reduce_of_the_producer_layer(dtype, n, h, w, cin,
     assert np.all(np.abs(a[:, 1] - e2) <= 2e-5 * mag2 + 1e-6)
 
 
-def test_double_conv_backward_same_with_and_without_fused_bn_reduce():
-    """blocks.double_conv_bwd with FUSE_BN_REDUCE on/off: identical input gradient, BN/conv gradients to summation order."""
-    from unetk import blocks
+@pytest.mark.parametrize('cin,cmid', [(128, 64), (64, 64)])
+def test_double_conv_backward_same_with_and_without_fused_bn_reduce(cin, cmid):
+    """blocks.double_conv_bwd with FUSE_BN_REDUCE on/off: identical input gradient, BN/conv gradients to summation
+    order.  The block's mid channel count is 64 -- the shape whose second conv's dgrad really carries the reduction
+    (asserted), so the two runs take different kernels."""
+    from unetk import blocks, ops
     from unet.unet_parts import DoubleConv
     torch.manual_seed(3)
-    dc = DoubleConv(64, 128).cuda().train()
-    x = _rand((2, 26, 37, 64), 21).to(torch.bfloat16).cuda()
-    da = _rand((2, 26, 37, 128), 22).to(torch.bfloat16).cuda()
+    dc = DoubleConv(cin, cmid).cuda().train()
+    assert ops.dgrad_bn_reduce_is_fused(cmid, cmid, torch.bfloat16)
+    x = _rand((2, 26, 37, cin), 21).to(torch.bfloat16).cuda()
+    da = _rand((2, 26, 37, cmid), 22).to(torch.bfloat16).cuda()
     outs = []
+    before = blocks.FUSE_BN_REDUCE
     for fuse in (False, True):
         blocks.FUSE_BN_REDUCE = fuse
         try:
@@ -161,7 +166,7 @@ def test_double_conv_backward_same_with_and_without_fused_bn_reduce():
             torch.cuda.synchronize()
             outs.append((dx.clone(), {k: v.clone() for k, v in grads.items()}))
         finally:
-            blocks.FUSE_BN_REDUCE = True
+            blocks.FUSE_BN_REDUCE = before
     (dx0, g0), (dx1, g1) = outs
     assert float((dx0.float() - dx1.float()).abs().max()) <= 1e-2 * float(dx0.float().abs().max())
     for p in g0:

@@ -1,9 +1,11 @@
 """SURVEY.md section 4's data-parallel invariant on the REAL backward: the gradients two ranks hold after one step on
 different images equal the average of the two single-rank gradients, and both ranks take the same optimizer step.
 
-Two child processes share the box's one GPU (RCCL refuses two ranks on one device, so the process group is `gloo` on
-CUDA tensors: the same FlatGrads code path -- completion-ordered flat buffer, buckets launched from inside the backward
-as blocks complete, wait before the clip -- with the collective itself swapped).  The single-rank references are the
+Two child processes share the box's one GPU (RCCL refuses two ranks on one device, so the process group is `gloo`,
+each bucket staged through the host -- torch's gloo path hangs on several in-flight device-tensor all-reduces between
+queued kernels on this stack: scripts/gloo_cuda_probe.py, profiles/r03_gloo_cuda_probe.log): the same FlatGrads code
+path -- completion-ordered flat buffer, buckets launched from inside the backward as blocks complete, wait before the
+clip -- with the collective itself swapped.  The single-rank references are the
 same worker run with world size 1 on each rank's images.  The 8-GPU RCCL run is the driver's."""
 import os
 import subprocess
@@ -16,6 +18,13 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, 'ddp_worker.py')
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:                 # a leaked rank of an earlier run must not turn into a rendezvous hang
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
 
 
 def _spawn(rank, world, port, out):
@@ -43,7 +52,8 @@ def test_two_rank_gradients_are_the_average_of_the_single_rank_gradients(tmp_pat
     two, one = tmp_path / 'two', tmp_path / 'one'
     two.mkdir()
     one.mkdir()
-    _wait([_spawn(r, 2, 29573, two) for r in (0, 1)], two)       # the pair, concurrently
+    port = _free_port()
+    _wait([_spawn(r, 2, port, two) for r in (0, 1)], two)        # the pair, concurrently
     for r in (0, 1):                                             # each rank's images alone (world size 1)
         _wait([_spawn(r, 1, 0, one)], one)
     d2 = [np.load(two / f'rank{r}.npz') for r in (0, 1)]

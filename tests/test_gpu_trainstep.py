@@ -160,8 +160,10 @@ def test_unfused_trainer_channels_last_clip_reaches_every_gradient():
 
 
 def test_fused_optimizer_state_dict_is_rmsprops_and_accumulation_is_refused():
-    """ClipRMSprop checkpoints in torch.optim.RMSprop's format: after two steps its state loads into a stock RMSprop
-    (and back) and both continue with the same third step.  A second backward without step()/zero_grad() raises
+    """ClipRMSprop checkpoints in torch.optim.RMSprop's format, numbered in net.parameters() order: after two steps
+    `torch.optim.RMSprop(net.parameters()).load_state_dict(clip.state_dict())` attaches every state tensor to the right
+    parameter, and the fused optimizer, a fused optimizer resumed from the stock one's checkpoint, and the stock
+    optimizer itself all take the same third step.  A second backward without step()/zero_grad() raises
     instead of silently dropping the first pass's gradients."""
     from unet import UNet
     from unetk.loss import segmentation_loss
@@ -179,21 +181,46 @@ def test_fused_optimizer_state_dict_is_rmsprops_and_accumulation_is_refused():
     nets[1].load_state_dict(nets[0].state_dict())
     tb = Trainer(nets[1], fused_optimizer=True, **kw)
     tb.optimizer.load_state_dict(sd)
-    # (b) a stock RMSprop checkpoint (module parameter order) into a third
+    # (b) straight into a stock RMSprop over net.parameters() (positional: stock.load_state_dict checks sizes only), and
+    #     that optimizer's own checkpoint back into a third fused trainer
     nets[2].load_state_dict(nets[0].state_dict())
     stock = torch.optim.RMSprop(nets[2].parameters(), lr=1e-3, weight_decay=1e-8, momentum=0.999, foreach=True)
-    by_param = {p: sd['state'][i] for i, p in enumerate(ta.sync.params)}
-    own = dict(zip(nets[0].parameters(), nets[2].parameters()))
-    for p0, p2 in own.items():
-        stock.state[p2] = {k: v.clone() for k, v in by_param[p0].items()}
+    stock.load_state_dict(sd)
+    for p0, p2 in zip(nets[0].parameters(), nets[2].parameters()):
+        off, n = ta.sync.offsets[id(p0)], p0.numel()
+        assert stock.state[p2]['square_avg'].shape == p2.shape
+        assert torch.equal(stock.state[p2]['square_avg'].reshape(-1), ta.optimizer.square_avg[off:off + n])
+        assert torch.equal(stock.state[p2]['momentum_buffer'].reshape(-1), ta.optimizer.momentum_buf[off:off + n])
     tc = Trainer(nets[2], fused_optimizer=True, **kw)
     tc.optimizer.load_state_dict(stock.state_dict())
+    # (c) the stock optimizer itself takes the third step (clip + step as train.py:115-116) on a fourth copy
+    net4 = _closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train()
+    net4.load_state_dict(nets[0].state_dict())
+    stock4 = torch.optim.RMSprop(net4.parameters(), lr=1e-3, weight_decay=1e-8, momentum=0.999, foreach=True)
+    stock4.load_state_dict(sd)
+    loss4 = segmentation_loss(net4(img), mask)
+    stock4.zero_grad(set_to_none=True)
+    loss4.backward()
+    torch.nn.utils.clip_grad_norm_(net4.parameters(), 1.0)
+    stock4.step()
     la, lb, lc = float(ta.step(img, mask)), float(tb.step(img, mask)), float(tc.step(img, mask))
-    assert abs(la - lb) <= 1e-6 * abs(la) and abs(la - lc) <= 1e-6 * abs(la)
+    assert abs(la - lb) <= 1e-6 * abs(la) and abs(la - lc) <= 1e-6 * abs(la) and abs(la - float(loss4)) <= 1e-6 * abs(la)
     pa = dict(nets[0].named_parameters())
-    for other in (nets[1], nets[2]):
+    for other in (nets[1], nets[2], net4):
         for k, p in other.named_parameters():
             assert l2_err(npy(p), npy(pa[k])) < 1e-5, k
+    # (d) a round-2 file of this class (gradient-completion order, no marker) still loads
+    mod_index = {id(q): j for j, q in enumerate(ta.sync.module_order)}
+    old = {'state': {i: {k: v.clone() for k, v in sd['state'][mod_index[id(p)]].items()}
+                     for i, p in enumerate(ta.sync.params)},
+           'param_groups': [{k: v for k, v in sd['param_groups'][0].items() if k != 'unetk_order'}]}
+    td = Trainer(_closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train(),
+                 fused_optimizer=True, **kw)
+    td.optimizer.load_state_dict(old)
+    for i, p in enumerate(ta.sync.module_order):
+        q = list(td.optimizer.fg.module_order)[i]
+        off, n = td.optimizer.fg.offsets[id(q)], q.numel()
+        assert torch.equal(td.optimizer.square_avg[off:off + n].view(q.shape), sd['state'][i]['square_avg'])
     # ---- accumulation
     with torch.autocast('cuda', dtype=torch.bfloat16, enabled=False):
         loss = segmentation_loss(nets[0](img), mask)
