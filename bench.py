@@ -13,8 +13,14 @@ tensors already resident in HBM: bf16-autocast forward, CE+dice loss, backward, 
 Rank 0 prints ONE JSON line with the whole-job images/sec plus
   roofline     -- the dominant kernel (NHWC implicit-GEMM conv3x3 on MFMA, fprop+dgrad launches of one step):
                   algorithmic FLOPs / HIP-event time on the launch stream, against the dense MFMA peak of the dtype
+  roofline_hbm -- the HBM-bound kernel families of the same step (BatchNorm+ReLU apply / backward reduce / backward
+                  apply incl. their pool and head variants, ConvTranspose2d, first layer, loss, optimizer):
+                  algorithmic bytes from the call arguments / HIP-event time, against 8 TB/s
   cpu_baseline -- the reference's PyTorch CPU path (oracle/unet_torch.py, a stock-torch.nn restatement) timed on
-                  the box's host cores on a bounded sample (batch 1), kind "port" (N = 1, default config only).
+                  the box's host cores on a bounded sample (batch 1), kind "port" (N = 1, default config only): the
+                  train step, and beside it BASELINE.json configs[0] (fp32 eval forward, N = 1).
+--force-collectives: run the gradient buckets through a 1-rank RCCL group (what one GPU can say about the
+data-parallel path: launch + stream hand-over + CU contention of RCCL's kernels against the whole-CU conv kernels).
 
 --config selects the other BASELINE.json configurations (same JSON, own roofline leg); the default is the headline:
   train959            configs[1]  UNet(3,2,False) bf16 train step, batch 16 @959x640
@@ -75,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--dry', action='store_true', help='CPU rehearsal of the rank plumbing; no kernels, no measurement')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='N = 1: all-reduce the gradient buckets in a 1-rank RCCL group anyway (overhead measurement)')
     return ap.parse_args(argv)
 
 
@@ -127,9 +135,22 @@ def cpu_baseline(seconds_budget=25.0):
         train_step(net, opt, img, mask)
         n += 1
     dt = (time.perf_counter() - t0) / n
+    # BASELINE.json configs[0] beside it: UNet(3,2,False) fp32 eval forward, N = 1 (unet_model.py:25-36)
+    net.eval()
+    with torch.no_grad():
+        net(img)                                        # warm-up
+        t1 = time.perf_counter()
+        m = 0
+        while m < 3 and (m == 0 or time.perf_counter() - t1 < 8.0):
+            net(img)
+            m += 1
+        dtf = (time.perf_counter() - t1) / m
     return {'value': 1.0 / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'{n} fp32 train steps (fwd+CE+dice+bwd+clip+RMSprop) of batch 1 at 959x640 after 1 warm-up, '
-                      f'torch {torch.__version__} CPU, {threads} threads'}
+                      f'torch {torch.__version__} CPU, {threads} threads',
+            'forward_n1': {'value': 1.0 / dtf, 'unit': 'images/sec', 'ms': 1e3 * dtf,
+                           'sample': f'{m} fp32 eval forwards of batch 1 at 959x640 (BASELINE.json configs[0]) after '
+                                     f'1 warm-up, same threads'}}
 
 
 def committed_profile(pattern, getter):
@@ -162,7 +183,7 @@ def dry_run(args, rank, world):
 
     def step():
         grads = sync.initial_grads()
-        for blk in FlatGrads._completion_blocks(net):
+        for blk in FlatGrads._completion_layers(net):
             for p in blk:
                 grads[p].fill_(float(rank + 1))
             sync.ready(blk, grads)
@@ -233,6 +254,10 @@ def main(argv=None):
     dev = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group(args.backend, device_id=dev if args.backend == 'nccl' else None)
+    elif args.force_collectives:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
     from unet import UNet
     from unetk import _native
@@ -253,7 +278,7 @@ def main(argv=None):
         masks = torch.randint(0, cfg['n_classes'], (B, hh, ww), device=dev, generator=g)
 
     if cfg['train']:
-        trainer = Trainer(net, amp=cfg['amp'])
+        trainer = Trainer(net, amp=cfg['amp'], force_collectives=args.force_collectives)
 
         def step():
             return trainer.step(images, masks)
@@ -282,7 +307,7 @@ def main(argv=None):
         elapsed = float(t)
     loss_val = float(res) if cfg['train'] else None
 
-    roofline = None
+    roofline = roofline_hbm = None
     # kernel timing pass: one more step (on EVERY rank: it contains the gradient collectives) with, on rank 0,
     # every C-ABI launch bracketed by HIP events on its stream
     if rank != 0:
@@ -330,6 +355,20 @@ def main(argv=None):
                 if mb:
                     roofline['mfma_busy_counters'] = mb['value']
                     roofline['mfma_busy_source'] = mb['source']
+        fams = kt.by_hbm_family()
+        if fams:
+            peak_gbs = 8000.0                              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+            def leg(n, ms_, b):
+                gbs = b / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+                return {'launches': n, 'ms_per_step': ms_, 'algorithmic_bytes': b, 'achieved': gbs, 'frac': gbs / peak_gbs}
+            roofline_hbm = {'bound': 'hbm', 'peak': peak_gbs, 'unit': 'GB/s',
+                            'families': {k: leg(*v) for k, v in sorted(fams.items(), key=lambda kv: -kv[1][1])}}
+            bn = [v for k, v in fams.items() if k.startswith('bn_')]
+            if bn:
+                roofline_hbm['batchnorm_family'] = leg(*[sum(v[i] for v in bn) for i in range(3)])
+            roofline_hbm['all'] = leg(*[sum(v[i] for v in fams.values()) for i in range(3)])
+            roofline_hbm['note'] = ('algorithmic bytes = every tensor a pass must read or write, once, from the call '
+                                    'arguments; time = HIP events around each launch on its stream (one step)')
         total_ms = sum(v[1] for v in table.values())
         sys.stderr.write('kernel-time table of one step (HIP events, serialised by the event brackets):\n')
         for name, (n, m, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):
@@ -354,10 +393,16 @@ def main(argv=None):
                        'optimizer': 'RMSprop+clip_grad_norm' if cfg['train'] else None,
                        'loss': 'CE+dice' if cfg['train'] else None},
             'model_tflops': ips * cfg['gflop'] * (hh * ww) / (cfg['h'] * cfg['w']) / 1e3, 'final_loss': loss_val,
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_hbm': roofline_hbm, 'cpu_baseline': cpu,
         }
+        if args.force_collectives:
+            out['force_collectives'] = {'backend': 'nccl', 'world': world,
+                                        'collectives_per_step': len(trainer.sync.launched) if cfg['train'] else 0,
+                                        'largest_bytes': 4 * max((b - a for a, b in trainer.sync.launched), default=0),
+                                        'last_bytes': 4 * (trainer.sync.launched[-1][1] - trainer.sync.launched[-1][0])
+                                        if cfg['train'] and trainer.sync.launched else 0}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

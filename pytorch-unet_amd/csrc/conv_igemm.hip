@@ -1129,10 +1129,20 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
     // bf16: the 16x16x32 kernel (conv3x3_k32.hip) and its weight format; the packer asks the same function
     if (conv3_use_k32(dtype == UNETK_BF16, P.Cout)) return unetk_internal_conv3x3_k32(&P, s);
-    if (P.aff_scale != nullptr) {     // inference epilogue (bf16 only: BASELINE.json configs[2])
+#ifdef UNETK_TUNING
+    // A/B builds only (UNETK_CONV_K32=0/1): the 32x32x16 bf16 instantiations of conv3x3_db_kernel, superseded by the
+    // 16x16x32 kernels above and not compiled into the shipped library
+    if (P.aff_scale != nullptr) {
       if (dtype != UNETK_BF16) return UNETK_ERR_DTYPE;
       return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2, true>(P, s) : launch_db<bf16, 2, 2, 8, 2, 2, true>(P, s);
     }
+    if (dtype == UNETK_BF16) {
+      if (P.bn_z != nullptr) return UNETK_ERR_UNFUSED;
+      return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<bf16, 2, 2, 8>(P, s);
+    }
+#endif
+    // from here on: fp32 (exact-fp32 MFMA); the inference epilogue exists in bf16 only (BASELINE.json configs[2])
+    if (dtype != UNETK_F32 || P.aff_scale != nullptr) return UNETK_ERR_DTYPE;
     // 128-channel tiles: 64-byte input rows (KI = 2) refilled every second weight chunk; 64-channel tiles: 16 x 32
     // pixels, 32-channel chunks (measured slower and removed: 32-byte rows for the wide tiles -7 %, 32 x 32-pixel
     // tiles with four row blocks per wave -6 %, two 4-wave workgroups per CU -10 %)
@@ -1140,9 +1150,8 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     // the epilogue is not overlapped with MFMA work, the extra read of z is exposed latency, and a fused version ran
     // exactly as long as dgrad followed by the stand-alone pass (measured at 128..1024 channels)
     if (P.bn_z != nullptr) return UNETK_ERR_UNFUSED;
-    if (cfg.NB == 4)
-      return dtype == UNETK_BF16 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<float, 4, 1, 8, 2, 2>(P, s);
-    return dtype == UNETK_BF16 ? launch_db<bf16, 2, 2, 8>(P, s) : launch_db<float, 2, 2, 8>(P, s);
+    if (cfg.NB == 4) return launch_db<float, 4, 1, 8, 2, 2>(P, s);
+    return launch_db<float, 2, 2, 8>(P, s);
   }
   if constexpr (MODE != 0) {
     if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)

@@ -102,20 +102,18 @@ class _UNetImpl:
             sums = None
             if isinstance(up.up, nn.ConvTranspose2d):
                 sums = ops.new_stats(up.conv.double_conv[0].in_channels, dlogits.device)
+            # OutConv's gradients come out of up4's BatchNorm backward (dhead): reported with that layer
+            first = [net.outc.conv.weight, net.outc.conv.bias] if (k == 3 and dhead is not None) else None
             dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None,
-                                          dx_sums=sums)
-            if k == 3 and dhead is not None:      # OutConv's gradients came out of up4's BatchNorm backward
-                done([net.outc.conv.weight, net.outc.conv.bias])
+                                          dx_sums=sums, done=done, done_first=first)
             dcats[k] = dcat
-            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True, dcat_sums=sums)
-            done(blocks.up_params(up))
+            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True, dcat_sums=sums, done=done)
         # encoder, deepest first.  A block's output fed the skip connection and the next block's max-pool: its
         # gradient = first half of dcat + scatter(pool gradient), formed inside the BatchNorm backward kernels
         dpool = None
         for k in (4, 3, 2, 1, 0):
             need_dx = k > 0 or needs[0]
-            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx, dpool=dpool)
-            done(blocks.double_conv_params(enc[k]))
+            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx, dpool=dpool, done=done)
             dpool = None
             if k > 0:
                 dcat = dcats[4 - k]

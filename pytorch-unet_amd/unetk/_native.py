@@ -97,7 +97,7 @@ class KernelTimer:
     default (zero overhead: the dict holds the raw ctypes functions)."""
 
     def __init__(self):
-        self.records = []      # (name, start_event, end_event, flops)
+        self.records = []      # (name, start_event, end_event, flops, device kernel, conv bytes, call arguments)
         self._saved = None
 
     @staticmethod
@@ -151,11 +151,81 @@ class KernelTimer:
         es = 2 if a[pos[1]] == BF16 else 4
         return float(es) * (n * h * w * (c_in + c_out) + 9 * c_in * c_out)
 
+    # HBM-bound families: name -> (family, algorithmic bytes) from the call's arguments (positions follow
+    # include/unetk.h): every tensor the pass must read or write, once, at its element size; per-channel vectors and
+    # fp64 accumulators (kilobytes) are left out.
+    @staticmethod
+    def _hbm(name, a):
+        def es(code):
+            return 2 if code == BF16 else 4
+        if name == 'unetk_bn_relu_apply':                     # read z, write act
+            return 'bn_apply', 2.0 * a[6] * a[7] * es(a[8])
+        if name == 'unetk_bn_relu_apply_pool':                # + the pooled tensor
+            n, h, w, c = a[8:12]
+            return 'bn_apply', (2.0 * n * h * w + n * (h // 2) * (w // 2)) * c * es(a[12])
+        if name == 'unetk_bn_relu_apply_head':                # + the logits
+            return 'bn_apply', (2.0 * a[12] + a[8]) * a[11] * es(a[13])
+        if name == 'unetk_bn_relu_bwd_reduce':                # read dout, z
+            return 'bn_bwd_reduce', 2.0 * a[9] * a[10] * es(a[11])
+        if name == 'unetk_bn_relu_bwd_reduce_pool':           # read dskip, z, dpool
+            n, h, w, c = a[11:15]
+            return 'bn_bwd_reduce', (2.0 * n * h * w + n * (h // 2) * (w // 2)) * c * es(a[15])
+        if name == 'unetk_bn_relu_bwd_reduce_head':           # read z, dlogits
+            return 'bn_bwd_reduce', (1.0 * a[13] + a[3]) * a[12] * es(a[14])
+        if name == 'unetk_bn_relu_bwd_apply':                 # read dout, z, write dz
+            return 'bn_bwd_apply', 3.0 * a[10] * a[11] * es(a[12])
+        if name == 'unetk_bn_relu_bwd_apply_pool':
+            n, h, w, c = a[12:16]
+            return 'bn_bwd_apply', (3.0 * n * h * w + n * (h // 2) * (w // 2)) * c * es(a[16])
+        if name == 'unetk_bn_relu_bwd_apply_head':            # read z, dlogits, write dz
+            return 'bn_bwd_apply', (2.0 * a[13] + a[3]) * a[12] * es(a[14])
+        if name == 'unetk_convT2x2_fwd':                      # read x, write 4 taps x c_out, weights once
+            n, h, w, ci, co = a[7:12]
+            return 'convT_fwd', (1.0 * n * h * w * (ci + 4 * co) + 4.0 * ci * co) * es(a[16])
+        if name == 'unetk_convT2x2_dgrad':
+            n, h, w, ci, co = a[6:11]
+            return 'convT_dgrad', (1.0 * n * h * w * (ci + 4 * co) + 4.0 * ci * co) * es(a[15])
+        if name == 'unetk_convT2x2_wgrad':                    # read x and the up-sampled gradient, write fp32 dw
+            n, h, w, ci, co = a[8:13]
+            return 'convT_wgrad', 1.0 * n * h * w * (ci + 4 * co) * es(a[18]) + 16.0 * ci * co
+        if name == 'unetk_conv3x3_first_fprop':               # read the fp32 image, write c_out channels
+            n, h, w, ci, co = a[6:11]
+            return 'first_layer', 1.0 * n * h * w * (4 * ci + co * es(a[11]))
+        if name == 'unetk_conv3x3_first_wgrad':               # read the image and dy
+            n, h, w, ci, co = a[7:12]
+            return 'first_layer', 1.0 * n * h * w * (4 * ci + co * es(a[12]))
+        if name == 'unetk_seg_loss_fwd':                      # logits + int64 mask
+            return 'loss', 1.0 * a[3] * (a[4] * es(a[8]) + 8)
+        if name == 'unetk_seg_loss_bwd':                      # logits + mask, write dlogits
+            return 'loss', 1.0 * a[3] * (2 * a[4] * es(a[9]) + 8)
+        if name == 'unetk_clip_rmsprop_step':                 # norm: read grad; step: read + write param, grad, 2 states
+            return 'optimizer', 36.0 * a[4]
+        if name == 'unetk_maxpool2x2_fwd':
+            n, h, w, c = a[4:8]
+            return 'pool_upsample', (1.0 * n * h * w + n * (h // 2) * (w // 2)) * c * es(a[8])
+        if name == 'unetk_bilinear2x_fwd':                    # read low-res, write the 2x window
+            n, h, w, c = a[4:8]
+            return 'pool_upsample', 5.0 * n * h * w * c * es(a[12])
+        if name == 'unetk_bilinear2x_bwd':
+            n, h, w, c = a[4:8]
+            return 'pool_upsample', 5.0 * n * h * w * c * es(a[12])
+        return None, 0.0
+
+    def by_hbm_family(self):
+        """{family: (launches, total_ms, total_algorithmic_bytes)} over the HBM-bound launches."""
+        out = {}
+        for rec in self.records:
+            fam, nbytes = self._hbm(rec[0], rec[6])
+            if fam is not None:
+                n, ms, b = out.get(fam, (0, 0.0, 0.0))
+                out[fam] = (n + 1, ms + rec[1].elapsed_time(rec[2]), b + nbytes)
+        return out
+
     def by_device_kernel(self):
         """{device kernel: (launches, total_ms, total_flops, total_algorithmic_bytes)} over the conv3x3 fprop/dgrad
         launches."""
         out = {}
-        for name, s, e, fl, kern, nbytes in self.records:
+        for name, s, e, fl, kern, nbytes, _ in self.records:
             if kern is not None:
                 n, ms, f, b = out.get(kern, (0, 0.0, 0.0, 0.0))
                 out[kern] = (n + 1, ms + s.elapsed_time(e), f + fl, b + nbytes)
@@ -173,7 +243,7 @@ class KernelTimer:
                 rc = _raw(*args)
                 e.record()
                 self.records.append((_name, s, e, self._flops(_name, args), self._device_kernel(_name, args),
-                                     self._conv_bytes(_name, args)))
+                                     self._conv_bytes(_name, args), args))
                 return rc
             fn[name] = timed
         return self
@@ -185,7 +255,7 @@ class KernelTimer:
     def summary(self):
         """{name: (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for name, s, e, fl, _, _ in self.records:
+        for name, s, e, fl, _, _, _ in self.records:
             n, ms, f = out.get(name, (0, 0.0, 0.0))
             out[name] = (n + 1, ms + s.elapsed_time(e), f + fl)
         return out

@@ -192,13 +192,14 @@ FUSE_BN_REDUCE = os.environ.get('UNETK_FUSE_BN_REDUCE', '1') != '0'
 
 
 def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None,
-                     bn_sums=None, bn_prev=None):
+                     bn_sums=None, bn_prev=None, done=None):
     """Backward of conv_bn_relu_fwd.  grads: dict param -> fp32 tensor to fill (allocated here if missing).
     dpool: gradient of the MaxPool2d(2) that also consumed this layer's output (`dact` is then the skip gradient).
     dhead: (dlogits, OutConv weight) when OutConv consumed this layer's output (`dact` is then None).
     dx_sums: zeroed [REPLICAS, c_in, 2] accumulator for the per-channel sums of the input gradient.
     bn_sums: this layer's BN-backward sums, already formed by the dgrad that wrote `dact`.
-    bn_prev: (z, BNState) of the layer that produced this layer's input: returns (dx, that layer's bn_sums)."""
+    bn_prev: (z, BNState) of the layer that produced this layer's input: returns (dx, that layer's bn_sums).
+    done: callback(params) invoked once this layer's parameter gradients are queued (gradient bucketing, unetk.ddp)."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
     if not _bn_uses_batch_stats(bn):
@@ -209,10 +210,14 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
     dw = _grad_buf(grads, conv.weight)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)
+        if done is not None:
+            done(conv_bn_params(conv, bn))
         if need_dx:
             raise RuntimeError('gradient w.r.t. the input image is not implemented (the reference never needs it)')
         return None
     ops.conv3x3_wgrad(x, dy, dw)
+    if done is not None:
+        done(conv_bn_params(conv, bn))       # before the dgrad launch: the collective overlaps it
     if not need_dx:
         return None
     return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums,
@@ -237,23 +242,42 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
     return a2, (s1, s2)
 
 
-def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None):
+def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None, done=None,
+                    done_first=None):
+    """done: per-layer completion callback (see conv_bn_relu_bwd); done_first: parameters that complete together with
+    the block's second layer (OutConv's, when its gradient comes out of this block's BatchNorm backward: `dhead`)."""
     seq = dc.double_conv
     s1, s2 = saved
     c_mid = seq[3].in_channels
+    done2 = done
+    if done is not None and done_first:
+        def done2(params):
+            done(done_first)
+            done(params)
     if FUSE_BN_REDUCE and ops.dgrad_bn_reduce_is_fused(c_mid, seq[3].out_channels, s1[1].dtype):
         # s1 = (x, z1, state1): the second conv consumed relu(bn(z1)), so its dgrad epilogue can reduce for BN 1
         da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead,
-                                      bn_prev=(s1[1], s1[2]))
+                                      bn_prev=(s1[1], s1[2]), done=done2)
     else:
-        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead), None
-    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums, bn_sums=sums1)
+        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead, done=done2), None
+    return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums, bn_sums=sums1,
+                            done=done)
+
+
+def conv_bn_params(conv, bn):
+    return [p for p in (conv.weight, bn.weight, bn.bias) if p is not None]
 
 
 def double_conv_params(dc):
     seq = dc.double_conv
     ps = [seq[0].weight, seq[1].weight, seq[1].bias, seq[3].weight, seq[4].weight, seq[4].bias]
     return [p for p in ps if p is not None]
+
+
+def double_conv_layers(dc):
+    """Parameter groups in the order double_conv_bwd completes them: second layer, then first."""
+    seq = dc.double_conv
+    return [conv_bn_params(seq[3], seq[4]), conv_bn_params(seq[0], seq[1])]
 
 
 # ------------------------------------------------------------------------------------ Up (both flavours)
@@ -285,13 +309,15 @@ def up_into_cat(up_mod, x_low, cat, c_skip, dtype):
     return (x_low, h, w, c_low, pad_t, pad_l)
 
 
-def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None):
+def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None, done=None):
     """dcat_sums: per-channel sums of dcat from the dgrad that wrote it (ConvTranspose2d bias gradient for free)."""
     x_low, h, w, c_low, pad_t, pad_l = saved
     if isinstance(up_mod, torch.nn.ConvTranspose2d):
         c_out = up_mod.out_channels
         ops.convT2x2_wgrad(x_low, dcat, c_skip, _grad_buf(grads, up_mod.weight), _grad_buf(grads, up_mod.bias), pad_t, pad_l,
                            sums=dcat_sums)
+        if done is not None:
+            done([up_mod.weight, up_mod.bias])
         if not need_dx:
             return None
         return ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out, h, w,
@@ -306,6 +332,14 @@ def up_params(up_block):
     if isinstance(up_block.up, torch.nn.ConvTranspose2d):
         ps += [up_block.up.weight, up_block.up.bias]
     return ps + double_conv_params(up_block.conv)
+
+
+def up_layers(up_block):
+    """Parameter groups of an Up block in completion order: its DoubleConv's two layers, then the ConvTranspose2d."""
+    out = double_conv_layers(up_block.conv)
+    if isinstance(up_block.up, torch.nn.ConvTranspose2d):
+        out.append([up_block.up.weight, up_block.up.bias])
+    return out
 
 
 # ------------------------------------------------------------------------------------ head

@@ -1,24 +1,32 @@
 """Gradient bucketing for the data-parallel train step (the reference itself has no distributed code).
 
-One process per GPU.  The whole-network autograd node (unet/unet_model.py) reports each block's parameters as
-soon as their gradients are final, in reverse execution order (outc, up4 ... up1, down4 ... inc).  FlatGrads lays
-all parameter gradients out in ONE fp32 buffer in exactly that order, so "the gradients finished so far" is always
-a contiguous range; whenever >= bucket_bytes are pending, that range is all-reduced (average) asynchronously on
-RCCL's stream while the remaining backward kernels keep the compute stream busy.  BatchNorm buffers are not
-touched: statistics stay per rank (north_star).
+One process per GPU.  The whole-network autograd node (unet/unet_model.py) reports each LAYER's parameters (a
+convolution and the BatchNorm behind it; a ConvTranspose2d; OutConv) as soon as their gradients are final, in reverse
+execution order (outc, up4 ... up1, down4 ... inc; inside a DoubleConv the second layer first).  FlatGrads lays all
+parameter gradients out in ONE fp32 buffer in exactly that order, so "the gradients finished so far" is always a
+contiguous range.  That range is all-reduced (average) asynchronously on RCCL's stream, while the remaining backward
+kernels keep the compute stream busy, whenever
+
+  * >= bucket_bytes are pending (25 MB: large enough for xGMI's per-link-bound rings to reach their bandwidth), or
+  * the pending range is at least as large as everything still to come (and >= min_bucket_bytes): the gradients
+    shrink geometrically towards the encoder's first layers, so waiting for a full bucket there would leave tens of
+    megabytes to a last, fully exposed collective after backward -- with this rule it is inc + down1, about 1 MB.
+
+A range larger than bucket_bytes (the 1024 -> 1024 convolution alone is 37.7 MB) goes out as equal pieces of at most
+bucket_bytes.  BatchNorm buffers are not touched: statistics stay per rank (north_star).
 """
 import torch
 import torch.distributed as dist
 
 
 class FlatGrads:
-    def __init__(self, net, process_group=None, bucket_bytes=25 << 20, force_collectives=False):
+    def __init__(self, net, process_group=None, bucket_bytes=25 << 20, force_collectives=False,
+                 min_bucket_bytes=1 << 20):
         self.module_order = [p for p in net.parameters()]     # torch.optim's order (checkpoints of a stock optimizer)
-        self.params = list(reversed(net.hot_path_params()))   # approximate completion order; ranges are re-derived
         order = []
-        for blk in self._completion_blocks(net):
-            order += blk
-        assert len(order) == len(self.params) and len(set(map(id, order))) == len(order)
+        for layer in self._completion_layers(net):
+            order += layer
+        assert len(order) == len(net.hot_path_params()) and len(set(map(id, order))) == len(order)
         self.params = order
         self.offsets, off = {}, 0
         for p in order:
@@ -28,6 +36,8 @@ class FlatGrads:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_elems = max(bucket_bytes // 4, 1)
+        self.min_bucket_elems = max(min(min_bucket_bytes, bucket_bytes) // 4, 1)
+        self.launched = []            # (lo, hi) element ranges of the collectives of the last backward pass, in order
         # force_collectives: run the bucketed all-reduces even in a 1-rank group (rehearses the RCCL path -- stream
         # hand-over, bucket ranges -- on a single GPU; the average over one rank is the identity)
         self.active = self.world > 1 or (force_collectives and dist.is_available() and dist.is_initialized())
@@ -42,14 +52,27 @@ class FlatGrads:
         net._initial_grads = self.initial_grads
 
     @staticmethod
-    def _completion_blocks(net):
+    def _completion_layers(net):
+        """Parameter groups in the order the whole-net backward reports them (blocks.double_conv_bwd / up_bwd)."""
         from . import blocks
         out = [[net.outc.conv.weight, net.outc.conv.bias]]
         for u in (net.up4, net.up3, net.up2, net.up1):
-            out.append(blocks.up_params(u))
+            out += blocks.up_layers(u)
         for d in (net.down4, net.down3, net.down2, net.down1):
-            out.append(blocks.double_conv_params(d.maxpool_conv[1]))
-        out.append(blocks.double_conv_params(net.inc))
+            out += blocks.double_conv_layers(d.maxpool_conv[1])
+        out += blocks.double_conv_layers(net.inc)
+        return [g for g in out if g]
+
+    @staticmethod
+    def _completion_blocks(net):
+        """The same order at block granularity (outc, up4 ... up1, down4 ... inc)."""
+        from . import blocks
+        out = [[net.outc.conv.weight, net.outc.conv.bias]]
+        for u in (net.up4, net.up3, net.up2, net.up1):
+            out.append([p for g in blocks.up_layers(u) for p in g])
+        for d in (net.down4, net.down3, net.down2, net.down1):
+            out.append([p for g in blocks.double_conv_layers(d.maxpool_conv[1]) for p in g])
+        out.append([p for g in blocks.double_conv_layers(net.inc) for p in g])
         return out
 
     def initial_grads(self):
@@ -64,6 +87,7 @@ class FlatGrads:
         self._unconsumed = True
         self._pending = [0, 0]
         self._works = []
+        self.launched = []
         self.views = {p: self.flat[self.offsets[id(p)]:self.offsets[id(p)] + p.numel()].view(p.shape)
                       for p in self.params}
         return dict(self.views)
@@ -88,22 +112,32 @@ class FlatGrads:
             return
         lo = min(self.offsets[id(p)] for p in params)
         hi = max(self.offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in params)
-        assert lo == self._pending[1], 'blocks must complete in layout order'
+        assert lo == self._pending[1], 'layers must complete in layout order'
         self._pending[1] = hi
-        if self.active and hi - self._pending[0] >= self.bucket_elems:
+        pending = hi - self._pending[0]
+        if self.active and (pending >= self.bucket_elems or
+                            pending >= max(self.total - hi, self.min_bucket_elems)):
             self._launch()
 
     def _launch(self):
         lo, hi = self._pending
         if hi > lo:
             op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
-            buf = self.flat[lo:hi]
-            if not self.native_avg and buf.is_cuda:
-                # gloo (rehearsals without RCCL, e.g. two ranks sharing one GPU): its collectives on device tensors
-                # hang on this ROCm stack, so the bucket is staged through the host -- same bucket ranges, same launch
-                # points inside the backward, same wait-before-clip; only the overlap is lost
-                buf = buf.cpu()
-            self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), lo, hi, buf))
+            pieces = -(-(hi - lo) // self.bucket_elems)       # equal pieces of at most bucket_elems, 16-byte aligned
+            step = -(-(hi - lo) // pieces)
+            step = (step + 3) // 4 * 4
+            for a in range(lo, hi, step):
+                b = min(a + step, hi)
+                buf = self.flat[a:b]
+                if not self.native_avg and buf.is_cuda:
+                    # gloo (rehearsals without RCCL, e.g. two ranks sharing one GPU): several asynchronous gloo
+                    # collectives on device tensors interleaved with queued kernels hang in Work.wait() on this stack
+                    # (plain-torch probe: profiles/r03_gloo_cuda_probe.log), so the bucket is staged through the host
+                    # -- same bucket ranges, same launch points inside the backward, same wait-before-clip; only the
+                    # overlap is lost
+                    buf = buf.cpu()
+                self._works.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), a, b, buf))
+                self.launched.append((a, b))
         self._pending = [hi, hi]
 
     def finish(self):

@@ -218,3 +218,124 @@ def test_bilinear_batch64_inference_fused_epilogue_matches_unfused():
     clear = margin > 2e-2 * p.abs().max()
     assert bool((f.argmax(1) == p.argmax(1))[clear].all())
     assert agree >= 0.999 or float(clear.float().mean()) < 0.999, agree
+
+
+def _ints_cuda(shape, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return torch.randint(-1, 2, shape, generator=g, device='cuda', dtype=torch.int8).bfloat16()
+
+
+@pytest.mark.parametrize('cin,cout', [(128, 64), (64, 64)])
+def test_batch8_1918x1280_image7_equals_the_same_image_alone(cin, cout):
+    """BASELINE.json configs[3] at its per-GPU batch: [8, 1280, 1918, 128] holds 2.51e9 elements (> 2^31) and
+    19.6 M pixels, so every per-image base, pixel index and byte offset is exercised beyond 32 bits.  Integer operands:
+    the last image of the batch must come out BIT-EXACTLY as when it is run alone (and as the im2col evaluation, which
+    the N = 1 cases above pin), for fprop + statistics, dgrad (whose 128-channel output is the > 2^31 tensor in the
+    128 -> 64 case), BatchNorm+ReLU apply and its backward apply."""
+    from unetk import ops, _native as nat
+    n, h, w = 8, 1280, 1918
+    x = _ints_cuda((n, h, w, cin), 31)
+    assert cin < 128 or x.numel() > 2 ** 31
+    wt = _ints((cout, cin, 3, 3), 32, min(1.0, 24.0 / (9 * cin))).cuda()
+    wpk = ops.pack_weight(0, wt, cout, cin, torch.bfloat16)
+    stats = ops.new_stats(cout, 'cuda')
+    y = ops.conv3x3_fprop(x, wpk, cout, stats=stats)
+    s_ref = torch.zeros((cout, 2), dtype=torch.float64, device='cuda')
+    for i in (0, 3, 7):
+        st1 = ops.new_stats(cout, 'cuda')
+        y1 = ops.conv3x3_fprop(x[i:i + 1], wpk, cout, stats=st1)
+        assert torch.equal(y[i], y1[0]), f'fprop image {i}'
+    ref = (_im2col(x[7:8].float()) @ wt.reshape(cout, cin * 9).t().contiguous()).reshape(h, w, cout)
+    assert torch.equal(y[7].float(), ref), 'fprop image 7 vs im2col'
+    del ref
+    yf = y.view(-1, cout)
+    for lo in range(0, yf.shape[0], 1 << 22):            # exact integer sums of the stored output, in slices
+        blk = yf[lo:lo + (1 << 22)].double()
+        s_ref[:, 0] += blk.sum(0)
+        s_ref[:, 1] += (blk * blk).sum(0)
+    assert torch.equal(stats.sum(0), s_ref), 'BatchNorm statistics over all 8 images'
+
+    # dgrad: the gradient tensor has cout channels, the result cin
+    dy = _ints_cuda((n, h, w, cout), 33)
+    wd = _ints((cout, cin, 3, 3), 34, min(1.0, 24.0 / (9 * cout))).cuda()
+    wpd = ops.pack_weight(1, wd, cout, cin, torch.bfloat16)
+    dx = ops.conv3x3_dgrad(dy, wpd, cin)
+    for i in (0, 7):
+        assert torch.equal(dx[i], ops.conv3x3_dgrad(dy[i:i + 1], wpd, cin)[0]), f'dgrad image {i}'
+    wrot = wd.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * 9).t().contiguous()
+    assert torch.equal(dx[7].float(), (_im2col(dy[7:8].float()) @ wrot).reshape(h, w, cin)), 'dgrad image 7 vs im2col'
+    del dy, y, yf
+
+    # BatchNorm + ReLU forward apply and backward apply on the [8, 1280, 1918, cin] tensors, fixed coefficients
+    g = torch.Generator().manual_seed(35)
+    st = ops.BNState(cin, 'cuda')
+    st.buf.copy_(torch.rand((4, cin), generator=g) + 0.5)
+    st.shift.sub_(1.0)
+    a = ops.bn_relu_apply(dx, st)
+    assert torch.equal(a[7], ops.bn_relu_apply(dx[7:8], st)[0]), 'bn_relu_apply image 7'
+    assert torch.equal(a[7].float(), torch.relu(dx[7].float() * st.scale + st.shift).bfloat16().float())
+    coef = (torch.rand((3, cin), generator=g) + 0.25).cuda()
+    dz = torch.empty_like(dx)
+    dz1 = torch.empty_like(dx[7:8])
+    for dout, z, out in ((x if cin == 128 else a, dx, dz), ((x if cin == 128 else a)[7:8], dx[7:8], dz1)):
+        nn_, hh_, ww_, c_, ld = ops.nhwc_meta(z, 'z')
+        nat.check(nat.fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), ops.nhwc_meta(dout, 'd')[4], z.data_ptr(), ld,
+                                                    st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
+                                                    coef.data_ptr(), out.data_ptr(), c_, nn_ * hh_ * ww_, c_, nat.BF16,
+                                                    ops.stream_ptr()), 'unetk_bn_relu_bwd_apply')
+    assert torch.equal(dz[7], dz1[0]), 'bn_relu_bwd_apply image 7'
+    assert bool((dz[7] != 0).any())
+    # the reduction pass over all 8 images = the sum of the eight single-image passes (a workgroup's partial sums are
+    # fp32, the accumulators across workgroups fp64: agreement to fp32 rounding, a wrong image would be off by O(1))
+    dout = x if cin == 128 else a
+    sums = ops.new_stats(cin, 'cuda')
+    one = torch.zeros((cin, 2), dtype=torch.float64, device='cuda')
+    npix1 = h * w
+    nat.check(nat.fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), cin, dx.data_ptr(), cin, st.scale.data_ptr(),
+                                                 st.shift.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(),
+                                                 sums.data_ptr(), n * npix1, cin, nat.BF16, ops.stream_ptr()), 'reduce')
+    for i in range(n):
+        s1 = ops.new_stats(cin, 'cuda')
+        nat.check(nat.fn['unetk_bn_relu_bwd_reduce'](dout[i:i + 1].data_ptr(), cin, dx[i:i + 1].data_ptr(), cin,
+                                                     st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
+                                                     st.invstd.data_ptr(), s1.data_ptr(), npix1, cin, nat.BF16,
+                                                     ops.stream_ptr()), 'reduce')
+        one += s1.sum(0)
+    got = sums.sum(0)
+    assert float((got - one).abs().max()) <= 1e-4 * float(one.abs().max())
+
+
+def test_cfg4_21_classes_fp32_512_batch16_train_step():
+    """BASELINE.json configs[4] at full size: UNet(3, 21) fp32 (no autocast), one train step on [16, 3, 512, 512]:
+    the fused multi-class CE + dice loss equals the reference's composition (train.py:102-111) evaluated by torch on
+    the logits the network produced, every gradient is finite, and the 21-class head went through conv1x1 kernels."""
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    from utils.dice_score import dice_loss
+    torch.manual_seed(0)
+    n, hh, ww, ncls = 16, 512, 512, 21
+    net = UNet(3, ncls, False).cuda().to(memory_format=torch.channels_last).train()
+    g = torch.Generator(device='cuda').manual_seed(7)
+    img = torch.rand((n, 3, hh, ww), device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    mask = torch.randint(0, ncls, (n, hh, ww), device='cuda', generator=g)
+    logits = net(img)
+    assert logits.shape == (n, ncls, hh, ww) and logits.dtype == torch.float32
+    loss = segmentation_loss(logits, mask)
+    loss.backward()
+    lf = logits.detach()
+    ref = F.cross_entropy(lf, mask) + dice_loss(F.softmax(lf, dim=1),
+                                                F.one_hot(mask, ncls).permute(0, 3, 1, 2).float(), multiclass=True)
+    assert abs(float(loss.detach()) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        assert float(p.grad.abs().max()) > 0, k
+    # the gradient of the loss w.r.t. the logits agrees with autograd through the reference's composition
+    lr = lf.clone().requires_grad_(True)
+    (F.cross_entropy(lr, mask) + dice_loss(F.softmax(lr, dim=1), F.one_hot(mask, ncls).permute(0, 3, 1, 2).float(),
+                                           multiclass=True)).backward()
+    from unetk import ops
+    out4 = ops.seg_loss_fwd(ops.to_nhwc(lf), mask)
+    out4 = out4[1] if isinstance(out4, tuple) else out4
+    dl = ops.seg_loss_bwd(ops.to_nhwc(lf), mask, out4)
+    got = ops.to_nchw(dl)
+    assert float((got - lr.grad).abs().max()) <= 1e-4 * float(lr.grad.abs().max())
