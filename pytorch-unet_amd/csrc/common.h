@@ -57,6 +57,24 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_add
       : "memory");
 }
 
+// 1 KiB of LDS-DMA through a buffer descriptor: lane -> 16 bytes at desc.base + soff + voff (ZEROS when voff is out
+// of the descriptor's range: scripts/microbench/buf_lds_oob.hip), LDS destination = lds_addr + lane * 16
+// (wave-uniform).  Hidden from the compiler like glds16_hidden; `s_nop 4`: the SGPR operands may be fresh from
+// v_readfirstlane (cdna_hip_programming 5.7).
+typedef __attribute__((ext_vector_type(4))) unsigned unetk_u32x4;
+__device__ __forceinline__ void bufdma16(unsigned voff, unetk_u32x4 desc, unsigned soff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
+      : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

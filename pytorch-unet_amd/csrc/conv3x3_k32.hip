@@ -56,22 +56,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned frag_t;      // one 16-byte
 
 __device__ uint4 g_zero_page_k32[8];
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-// 1 KiB of LDS-DMA through a buffer descriptor: lane -> 16 bytes at desc.base + soff + voff (zeros when voff is out of
-// the descriptor's range), LDS destination = lds_addr + lane * 16 (wave-uniform).  Hidden from the compiler like
-// glds16_hidden (common.h); `s_nop 4`: the SGPR operands may be fresh from v_readfirstlane (cdna_hip_programming 5.7).
-__device__ __forceinline__ void bufdma16(unsigned voff, u32x4 desc, unsigned soff, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 4\n\t"
-      "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(lds_addr), "s"(desc), "s"(soff)
-      : "memory");
-}
+typedef unetk_u32x4 u32x4;      // bufdma16 (common.h): LDS-DMA through a buffer descriptor, out-of-range lanes zero-filled
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N-1 (the loop index feeds constexpr contexts)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
