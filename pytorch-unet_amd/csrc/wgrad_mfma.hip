@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(512) void wgradT_bf16_kernel(WgradTParams P) {
 // 128-byte runs (32 cols), the parameter gradient written in runs of 8*taps floats.  Fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                            int nsplit, int taps, int rows, int cols, long s_row,
-                                                           long s_col, int accumulate) {
+                                                           long s_col, int accumulate, int tap_flip) {
   __shared__ float tile[9 * 8 * 33];
   const int col_tiles = cols / 32;
   const int c0 = (blockIdx.x % col_tiles) * 32, r0 = (blockIdx.x / col_tiles) * 8;
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int e = threadIdx.x; e < 32 * per_col; e += 256) {
     const int c = e / per_col, rem = e - c * per_col;
     const int r = rem / taps, t = rem - r * taps;
-    float* o = out + (long)(c0 + c) * s_col + (long)(r0 + r) * s_row + t;
+    float* o = out + (long)(c0 + c) * s_col + (long)(r0 + r) * s_row + (tap_flip ? taps - 1 - t : t);
     const float v = tile[(t * 8 + r) * 33 + c];
     *o = accumulate ? *o + v : v;
   }
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // weight tensor (the 64..128-channel layers), where the transposing kernel above would have too few workgroups.
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 int nsplit, int taps, int rows, int cols, long s_row,
-                                                                long s_col, int accumulate) {
+                                                                long s_col, int accumulate, int tap_flip) {
   // 64 outputs x 4 split groups per block, four independent partial sums per thread, groups combined in a fixed
   // order through LDS: 16x the loads in flight of a thread-per-output loop (which ran at 1 TB/s on 40-75 MB slabs)
   __shared__ float part[4][64];
@@ -1093,23 +1093,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
       const long rem = idx / cols;
       const int row = (int)(rem % rows);
       const int tap = (int)(rem / rows);
-      float* o = out + row * s_row + col * s_col + tap;
+      float* o = out + row * s_row + col * s_col + (tap_flip ? taps - 1 - tap : tap);
       *o = accumulate ? *o + s : s;
     }
     __syncthreads();
   }
 }
 
+// swapped: the slab holds [tap'][co][ci] with tap' = 8 - tap (the kernel ran with dy as the shifted operand, see
+// unetk_conv3x3_wgrad): rows = co, cols = ci, taps mirrored
 void launch_wgrad_reduce(const float* slab, float* out, int nsplit, int taps, int rows, int cols, int accumulate,
-                         hipStream_t stream) {
-  const long s_row = taps, s_col = (long)rows * taps;
+                         hipStream_t stream, bool swapped = false) {
+  const long s_row = swapped ? (long)cols * taps : taps, s_col = swapped ? taps : (long)rows * taps;
+  const int flip = swapped ? 1 : 0;
   if (nsplit <= 16) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((cols / 32) * (rows / 8))), dim3(256), 0, stream, slab, out,
-                       nsplit, taps, rows, cols, s_row, s_col, accumulate);
+                       nsplit, taps, rows, cols, s_row, s_col, accumulate, flip);
   } else {
     const long total = (long)taps * rows * cols;
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, slab, out,
-                       nsplit, taps, rows, cols, s_row, s_col, accumulate);
+                       nsplit, taps, rows, cols, s_row, s_col, accumulate, flip);
   }
 }
 
@@ -1279,6 +1282,9 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
       // ... or (wgrad5) over 32 x 4 pixels of the vertically stacked batch
       const int64_t s5 = pick_nsplit3(host_cdiv((long)n * (h + 1), 32) * host_cdiv(w, 4), (c_in / 64) * (c_out / 128));
       if (s5 > slabs) slabs = s5;
+    } else if (c_in % 128 == 0) {   // wgrad5 with the operands' roles swapped
+      const int64_t s5 = pick_nsplit3(host_cdiv((long)n * (h + 1), 32) * host_cdiv(w, 4), (c_out / 64) * (c_in / 128));
+      if (s5 > slabs) slabs = s5;
     }
   }
   if (kind == 1 && c_in % 128 == 0) {   // second-generation kernel: 2 x 32-pixel tiles, 64 x 128 channel pairs
@@ -1320,21 +1326,31 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
   UNETK_KNOB(gen5, "UNETK_WGRAD_K32", 1);    // 0: A/B against wgrad4 (32x32x16)
   // wgrad5 (16x16x32, 32-row columns over the vertically stacked batch): a tile's 34 halo rows may reach into ONE more
   // image, and its DMA offsets span two images
-  if (c_out % 128 == 0 && wide && gen5 && h + 1 >= 34 &&
+  // Its wide (128-channel) operand is the UNSHIFTED one.  c_out % 128 == 0: x shifted, dy fixed.  Otherwise, if
+  // c_in % 128 == 0 (the decoder's 128 -> 64 layer): the same sum re-indexed by the input pixel p' = p + tap,
+  //   dw[tap][ci][co] = sum_p' dy[p' - tap][co] * x[p'][ci]      (dy is zero outside the image, as the padding of x was)
+  // i.e. the kernel with dy as the shifted 64-channel operand, x as the fixed one, and mirrored taps (`swapped`).
+  const bool w5_direct = c_out % 128 == 0, w5_swapped = !w5_direct && c_in % 128 == 0;
+  if ((w5_direct || w5_swapped) && wide && gen5 && h + 1 >= 34 &&
       (int64_t)h * w * (ldx > lddy ? ldx : lddy) * 4 < (int64_t)1 << 31) {
     Wgrad5Params P{};
-    P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
-    P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+    P.slab = (float*)workspace;
+    P.N = n; P.H = h; P.W = w;
+    if (w5_direct) {
+      P.a = (const bf16*)x; P.b = (const bf16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+    } else {
+      P.a = (const bf16*)dy; P.b = (const bf16*)x; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
+    }
     P.tiles_x = host_cdiv(w, 4);
     P.ntiles = host_cdiv((long)n * (h + 1), 32) * P.tiles_x;
-    P.row_tiles = c_in / 64; P.col_tiles = c_out / 128;
+    P.row_tiles = P.Ca / 64; P.col_tiles = P.Cb / 128;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
     const size_t lds = 2 * W5_BUF + W5_SLOTS * 512 * 4;
     UNETK_ALLOW_LDS((wgrad5_bf16_kernel), lds);
     hipLaunchKernelGGL(wgrad5_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                        (hipStream_t)stream, P);
     UNETK_CHECK_LAUNCH();
-    launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
+    launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, P.Ca, P.Cb, accumulate, (hipStream_t)stream, w5_swapped);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }

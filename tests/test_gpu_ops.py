@@ -26,7 +26,8 @@ def _np(t):
 # (h >= 33 with c_out % 128 == 0: the 16x16x32 kernel, whose 32-row pixel columns run over the vertically stacked batch:
 #  34 virtual rows per image is its smallest case, 3 x 34 = 102 rows leave a ragged last tile, w = 7 a ragged column)
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 8, 32, 64, 64), (2, 16, 23, 64, 128), (3, 13, 70, 128, 64),
-                                            (3, 33, 7, 64, 128), (2, 45, 18, 128, 256), (5, 40, 9, 64, 128)])
+                                            (3, 33, 7, 64, 128), (2, 45, 18, 128, 256), (5, 40, 9, 64, 128),
+                                            (2, 35, 10, 128, 64)])   # ... and with the operands' roles swapped
 def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
     from oracle import ops_numpy as O
     from unetk import ops
