@@ -606,17 +606,32 @@ __device__ __forceinline__ frag5_t tr_read8u(int addr0, int addr1, int imm) {
   return __builtin_bit_cast(frag5_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// NCO = 128: as described above.  NCO = 64 (c_out and c_in both not multiples of 128, i.e. the 64 -> 64 layers): the dy
+// tile is 32 x 4 pixels x 128 B, stored like the x halo as two planes of 64 B per pixel (pitch 5 pixels); waves = 2
+// (32 ci) x 2 (32 co) x 2 COLUMN GROUPS: group g takes dy columns 2g, 2g+1 against halo columns 2g..2g+3 (four column
+// steps, 72 MFMAs per wave and tile) and writes its own partial-sum slab -- the split reduction adds 2 x nsplit slabs.
+template <int NCO>
 __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
+  constexpr bool WIDE = NCO == 128;
+  constexpr int NSTEP = WIDE ? 6 : 4;                    // halo columns a wave walks per tile
+  constexpr int NBC = WIDE ? 4 : 2;                      // dy columns a wave holds (ring)
+  constexpr int B_PLANE = 32 * 5 * 64;                   // NCO = 64: bytes per co plane
+  constexpr int B_PIECES = WIDE ? W5_B_PIECES : 2 * B_PLANE / 1024;   // 32 / 20
+  constexpr int PIECES = W5_A_PIECES + B_PIECES;         // 62 / 50
+  constexpr int BUF = PIECES * 1024;
+  constexpr int SLOTS = (PIECES + 7) / 8;                // 8 / 7
+  // (NCO = 64 with THREE buffers and two tiles of DMA look-ahead ran exactly as fast as with two -- 0.752 vs 0.755 ms at
+  // 64 -> 64, 16 x 640 x 959: that variant is bound by the LDS port (28 fragment KiB per 72 MFMAs), not by latency)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wid >> 2, wj = wid & 3;
+  const int wi = wid >> 2, wj = WIDE ? (wid & 3) : ((wid >> 1) & 1), grp = WIDE ? 0 : (wid & 1);
 
   const int npairs = P.row_tiles * P.col_tiles;
   int lin = blockIdx.x;                           // XCD-major, see wgrad3
   if ((gridDim.x & 7) == 0) lin = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int pair = lin % npairs, split = lin / npairs;
-  const int r0 = (pair / P.col_tiles) * 64, c0 = (pair % P.col_tiles) * 128;
+  const int r0 = (pair / P.col_tiles) * 64, c0 = (pair % P.col_tiles) * NCO;
   const int t_begin = (int)((long)P.ntiles * split / P.nsplit);
   const int t_end = (int)((long)P.ntiles * (split + 1) / P.nsplit);
   const int VH = P.H + 1;                         // virtual rows per image
@@ -633,18 +648,22 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int row = kh + k;
-      addrA[kh][rd] = (int)lds0 + (row * W5_AP) * 64 + (((wi ^ ((row >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
+      addrA[kh][rd] = (int)lds0 + (row * W5_AP + 2 * grp) * 64 + (((wi ^ ((row >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
     }
 #pragma unroll
-    for (int co = 0; co < 2; ++co)
-      addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 4) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
+    for (int co = 0; co < 2; ++co) {
+      if constexpr (WIDE)
+        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 4) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
+      else     // co plane = immediate (addrB[1] unused)
+        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 5 + 2 * grp) * 64 + (((wj ^ ((k >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
+    }
   }
 
   // ---- DMA: slot q of this wave is piece fi = q * 8 + wid (wave-uniform: x or dy); what a lane of it copies is fixed
   //      for the launch: virtual row hr (rel. to the tile, halo row 0 = tile row - 1), column hc (rel., halo column
   //      0 = tile column - 1) and the logical 16-byte piece of the pixel
   auto slot_geom = [&](int q, int lane, int& hr, int& hc, int& piece) {
-    const int fi = min(q * 8 + wid, W5_PIECES - 1);
+    const int fi = min(q * 8 + wid, PIECES - 1);
     if (fi < W5_A_PIECES) {
       const int s = fi * 64 + lane;
       const int plane = s >= W5_A_SLOTS / 2 ? 1 : 0;
@@ -654,16 +673,25 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
       hc = px - hr * W5_AP;
       piece = 4 * ((sl >> 1) ^ ((hr >> 3) & 1)) + 2 * plane + (sl & 1);
       if (hc >= 6 || hr >= 34) hr = 255;                     // pitch padding / beyond the planes: never valid
-    } else {
+    } else if constexpr (WIDE) {
       const int p = (fi - W5_A_PIECES) * 4 + (lane >> 4), ls = lane & 15;
       hr = (p >> 2) + 1;
       hc = (p & 3) + 1;
       piece = ls ^ swz5b(p >> 2);
+    } else {
+      const int s = (fi - W5_A_PIECES) * 64 + lane;
+      const int plane = s >= B_PLANE / 16 ? 1 : 0;
+      const int sp = s - plane * (B_PLANE / 16);
+      const int px = sp >> 2, sl = sp & 3;
+      const int r = px / 5, c = px - r * 5;
+      hr = c < 4 ? r + 1 : 255;                              // pitch padding: never valid
+      hc = c + 1;
+      piece = 4 * ((sl >> 1) ^ ((r >> 3) & 1)) + 2 * plane + (sl & 1);
     }
   };
   unsigned hc_pack = 0;                                        // 4 bits per slot: hc
 #pragma unroll
-  for (int q = 0; q < W5_SLOTS; ++q) {
+  for (int q = 0; q < SLOTS; ++q) {
     int hr, hc, piece;
     slot_geom(q, lane, hr, hc, piece);
     hc_pack |= (unsigned)hc << (4 * q);
@@ -684,7 +712,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   //      The eight offsets of a lane live in LDS behind the buffers ([slot][thread]; registers are all taken): a
   //      lane reads back what it wrote itself, one slot ahead of its use.
   int s_tx, s_yb, s_img;
-  const int vo_addr = (int)lds0 + 2 * W5_BUF + tid * 4;
+  const int vo_addr = (int)lds0 + 2 * BUF + tid * 4;
   const AS3 char* lds3 = reinterpret_cast<const AS3 char*>(0);
   auto vo_load = [&](int q) { return *reinterpret_cast<const AS3 unsigned*>(lds3 + vo_addr + q * 2048); };
   unetk_u32x4 dsc_a = {0u, 0u, 0u, 0x00020000u}, dsc_b = {0u, 0u, 0u, 0x00020000u};
@@ -700,10 +728,10 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));      // opaque: the geometry is recomputed here, not kept in 24 registers
 #pragma unroll
-    for (int q = 0; q < W5_SLOTS; ++q) {
+    for (int q = 0; q < SLOTS; ++q) {
       int hr, hc, piece;
       slot_geom(q, lane_o, hr, hc, piece);
-      const bool is_a = min(q * 8 + wid, W5_PIECES - 1) < W5_A_PIECES;
+      const bool is_a = min(q * 8 + wid, PIECES - 1) < W5_A_PIECES;
       int yl = s_yb + hr - 1;
       const bool wrap = yl >= VH && hr != 255;
       yl -= wrap ? VH : 0;
@@ -729,7 +757,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
     }
   };
   auto issue_piece = [&](int q, unsigned voff_q, unsigned buf, bool live) {     // branch-free, 5 VALU
-    const int fi = min(q * 8 + wid, W5_PIECES - 1);
+    const int fi = min(q * 8 + wid, PIECES - 1);
     const bool is_a = fi < W5_A_PIECES;                         // wave-uniform
     unsigned hp = hc_pack;
     asm volatile("" : "+v"(hp));     // opaque: otherwise the eight fields are extracted once, kept and spilled
@@ -743,17 +771,18 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 
   if (t_begin < t_end) {
 #pragma unroll
-    for (int q = 0; q < W5_SLOTS; ++q) issue_piece(q, vo_load(q), lds0, true);
+    for (int q = 0; q < SLOTS; ++q) issue_piece(q, vo_load(q), lds0, true);
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   int cur = 0;
 
-  frag5_t fa[3][2], fb[4][2];
+  frag5_t fa[3][2], fb[NBC][2];
   auto read_a = [&](int kh, int ci, int cc) {                  // A fragment (kh, ci half) of halo column cc
     fa[kh][ci] = tr_read8u(addrA[kh][0], addrA[kh][1], ci * W5_A_PLANE + cc * 64);
   };
   auto read_b = [&](int co, int c) {                           // dy fragment (co half) of column c
-    fb[c & 3][co] = tr_read8u(addrB[co][0], addrB[co][1], c * 256);
+    if constexpr (WIDE) fb[c & 3][co] = tr_read8u(addrB[co][0], addrB[co][1], c * 256);
+    else fb[c & 1][co] = tr_read8u(addrB[0][0], addrB[0][1], co * B_PLANE + c * 64);
   };
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
@@ -763,14 +792,14 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   read_b(1, 0);
 
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const unsigned nbuf = lds0 + (cur ^ 1) * W5_BUF;
-    const int flip = cur ? -W5_BUF : W5_BUF;
+    const unsigned nbuf = lds0 + (cur ^ 1) * BUF;
+    const int flip = cur ? -BUF : BUF;
     const bool next = tile + 1 < t_end;
     advance_stage();                                           // s_* now name tile + 1 (its pieces go out below)
     unsigned vo = vo_load(0);                                  // offset of the next piece to go out
 #pragma unroll
-    for (int cc = 0; cc < 6; ++cc) {
-      const bool last = cc == 5;
+    for (int cc = 0; cc < NSTEP; ++cc) {
+      const bool last = cc == NSTEP - 1;
       if (last) {
         // next tile landed (this wave's DMAs), and this wave holds every fragment it still needs of the current buffer:
         // from here on every read targets the next buffer
@@ -780,11 +809,11 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) addrA[kh][rd] += flip;
           addrB[0][rd] += flip;
-          addrB[1][rd] += flip;
+          if constexpr (WIDE) addrB[1][rd] += flip;
         }
       }
       // dy column for the NEXT step goes into the ring slot that step cc - 3 used last
-      if (cc + 1 < 4) {
+      if (cc + 1 < NBC) {
         read_b(0, cc + 1);
         read_b(1, cc + 1);
       } else if (last) {
@@ -799,21 +828,24 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int bl = cc - kw;
-            if (bl >= 0 && bl < 4) {
+            if (bl >= 0 && bl < NBC) {
 #pragma unroll
               for (int co = 0; co < 2; ++co)
                 acc[kh * 3 + kw][ci][co] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, fa[kh][ci]), __builtin_bit_cast(bf16x8, fb[bl & 3][co]),
+                    __builtin_bit_cast(bf16x8, fa[kh][ci]), __builtin_bit_cast(bf16x8, fb[bl & (NBC - 1)][co]),
                     acc[kh * 3 + kw][ci][co], 0, 0, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
           // this fragment's last use is behind us: fetch it for the next column (of the next tile after the last)
           read_a(kh, ci, last ? 0 : cc + 1);
-          // DMA of the next tile: pieces 0..7 behind the first two fragment groups of column steps 0..3
-          if (cc < 4 && kh == 0) {
-            issue_piece(2 * cc + ci, vo, nbuf, next);
-            if (2 * cc + ci + 1 < W5_SLOTS) vo = vo_load(2 * cc + ci + 1);
+          // DMA of the next tile: behind the first two (NCO = 64: three) fragment groups of the column steps before
+          // the last two
+          constexpr int PER = WIDE ? 2 : 3;
+          const int j = kh * 2 + ci, slot = PER * cc + j;
+          if (j < PER && cc < NSTEP - 1 && slot < SLOTS) {
+            issue_piece(slot, vo, nbuf, next);
+            if (slot + 1 < SLOTS) vo = vo_load(slot + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -822,7 +854,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   }
 
   const int col = lane & 15, rg = lane >> 4;
-  float* out = P.slab + (size_t)split * 9 * P.Ca * P.Cb;
+  float* out = P.slab + (size_t)(WIDE ? split : 2 * split + grp) * 9 * P.Ca * P.Cb;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1282,7 +1314,10 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
       // ... or (wgrad5) over 32 x 4 pixels of the vertically stacked batch
       const int64_t s5 = pick_nsplit3(host_cdiv((long)n * (h + 1), 32) * host_cdiv(w, 4), (c_in / 64) * (c_out / 128));
       if (s5 > slabs) slabs = s5;
-    } else if (c_in % 128 == 0) {   // wgrad5 with the operands' roles swapped
+    } else if (c_in % 128 != 0) {   // wgrad5<64>: two column groups, each with its own slab per split
+      const int64_t s5 = 2 * (int64_t)pick_nsplit3(host_cdiv((long)n * (h + 1), 32) * host_cdiv(w, 4), (c_in / 64) * (c_out / 64));
+      if (s5 > slabs) slabs = s5;
+    } else {                        // wgrad5 with the operands' roles swapped
       const int64_t s5 = pick_nsplit3(host_cdiv((long)n * (h + 1), 32) * host_cdiv(w, 4), (c_out / 64) * (c_in / 128));
       if (s5 > slabs) slabs = s5;
     }
@@ -1331,6 +1366,27 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
   //   dw[tap][ci][co] = sum_p' dy[p' - tap][co] * x[p'][ci]      (dy is zero outside the image, as the padding of x was)
   // i.e. the kernel with dy as the shifted 64-channel operand, x as the fixed one, and mirrored taps (`swapped`).
   const bool w5_direct = c_out % 128 == 0, w5_swapped = !w5_direct && c_in % 128 == 0;
+  UNETK_KNOB(gen5n, "UNETK_WGRAD_K32N", 1);  // 0: A/B of the 64 x 64 variant against wgrad3
+  if (!w5_direct && !w5_swapped && wide && gen5 && gen5n && h + 1 >= 34 &&
+      (int64_t)h * w * (ldx > lddy ? ldx : lddy) * 4 < (int64_t)1 << 31) {
+    // neither operand is 128 wide (64 -> 64): 64 x 64 channel tiles, two column groups -> 2 x nsplit partial slabs
+    Wgrad5Params P{};
+    P.slab = (float*)workspace;
+    P.N = n; P.H = h; P.W = w;
+    P.a = (const bf16*)x; P.b = (const bf16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+    P.tiles_x = host_cdiv(w, 4);
+    P.ntiles = host_cdiv((long)n * (h + 1), 32) * P.tiles_x;
+    P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
+    P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
+    const size_t lds = 2 * (50 * 1024) + 7 * 512 * 4;
+    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64>), lds);
+    hipLaunchKernelGGL(wgrad5_bf16_kernel<64>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                       (hipStream_t)stream, P);
+    UNETK_CHECK_LAUNCH();
+    launch_wgrad_reduce((const float*)workspace, dw, 2 * P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
+    UNETK_CHECK_LAUNCH();
+    return UNETK_OK;
+  }
   if ((w5_direct || w5_swapped) && wide && gen5 && h + 1 >= 34 &&
       (int64_t)h * w * (ldx > lddy ? ldx : lddy) * 4 < (int64_t)1 << 31) {
     Wgrad5Params P{};
@@ -1346,8 +1402,8 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.row_tiles = P.Ca / 64; P.col_tiles = P.Cb / 128;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
     const size_t lds = 2 * W5_BUF + W5_SLOTS * 512 * 4;
-    UNETK_ALLOW_LDS((wgrad5_bf16_kernel), lds);
-    hipLaunchKernelGGL(wgrad5_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128>), lds);
+    hipLaunchKernelGGL(wgrad5_bf16_kernel<128>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                        (hipStream_t)stream, P);
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, P.Ca, P.Cb, accumulate, (hipStream_t)stream, w5_swapped);

@@ -27,7 +27,8 @@ def _np(t):
 #  34 virtual rows per image is its smallest case, 3 x 34 = 102 rows leave a ragged last tile, w = 7 a ragged column)
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 8, 32, 64, 64), (2, 16, 23, 64, 128), (3, 13, 70, 128, 64),
                                             (3, 33, 7, 64, 128), (2, 45, 18, 128, 256), (5, 40, 9, 64, 128),
-                                            (2, 35, 10, 128, 64)])   # ... and with the operands' roles swapped
+                                            (2, 35, 10, 128, 64),     # ... with the operands' roles swapped
+                                            (3, 37, 11, 64, 64), (1, 70, 6, 192, 64)])   # ... its 64 x 64 variant
 def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
     from oracle import ops_numpy as O
     from unetk import ops
