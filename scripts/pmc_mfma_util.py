@@ -18,7 +18,7 @@ def main():
     db, out = sys.argv[1:3]
     c = sqlite3.connect(db)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    fam = r'(conv3x3_db_kernel|conv3x3_k32n64_kernel|conv3x3_k32_kernel|wgrad4_bf16_kernel|wgrad3_bf16_kernel|wgradT_bf16_kernel|pw_db_kernel|wgrad_bf16_kernel)'
+    fam = r'(conv3x3_db_kernel|conv3x3_k32n64_kernel|conv3x3_k32_kernel|wgrad5_bf16_kernel|wgrad4_bf16_kernel|wgrad3_bf16_kernel|wgradT_bf16_kernel|pw_db_kernel|wgrad_bf16_kernel)'
     for name, cn, v in c.execute('select kernel_name, counter_name, value from counters_collection'):
         m = re.search(fam, name)
         if m:
