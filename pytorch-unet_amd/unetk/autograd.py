@@ -35,8 +35,10 @@ class BlockFn(torch.autograd.Function):
                 dx = ops.to_nchw(dx)
                 outs.append(dx if dx.dtype == dt else dx.to(dt))
         pg = []
+        # (a trainer that steps from the flat gradient buffer takes the gradients there: unetk.ddp.FlatGrads)
+        deliver = getattr(getattr(ctx.impl, 'net', None), '_grads_via_autograd', True)
         for p, need in zip(ctx.params, ctx.needs_input_grad[2 + ctx.n_inputs:]):
-            gp = grads.get(p) if need else None
+            gp = grads.get(p) if (need and deliver) else None
             if gp is not None and gp.dtype != p.dtype:
                 gp = gp.to(p.dtype)
             pg.append(gp)

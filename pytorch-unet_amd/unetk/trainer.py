@@ -22,7 +22,7 @@ class Trainer:
         self.net = net
         self.amp = amp
         self.clip = gradient_clipping
-        self.sync = FlatGrads(net, process_group, bucket_bytes, force_collectives)
+        self.sync = FlatGrads(net, process_group, bucket_bytes, force_collectives, grads_to_autograd=False)
         self.fused = fused_optimizer
         if fused_optimizer:
             from .optim import ClipRMSprop
