@@ -964,7 +964,8 @@ template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t
   int tpb = 1;
   {
     double best = 1e30;                                       // whole rounds of 256 workgroups (see launch_k32)
-    for (int t = 1; t <= 16; ++t) {
+    UNETK_KNOB(tpb_max, "UNETK_CONV_TPB_MAX", 96);
+    for (int t = 1; t <= tpb_max; ++t) {
       const long wgs = (ntiles + t - 1) / t;
       const long rounds = (wgs + 255) / 256;
       const double cost = (double)rounds * ((double)t * nstages + 1.5);
@@ -998,7 +999,8 @@ template <int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hip
   int tpb = 1;
   {
     double best = 1e30;
-    for (int t = 1; t <= 16; ++t) {
+    UNETK_KNOB(tpb_max, "UNETK_CONV_TPB_MAX", 96);
+    for (int t = 1; t <= tpb_max; ++t) {
       const long wgs = ((ntiles + t - 1) / t) * Q.n_tiles;
       const long rounds = (wgs + 255) / 256;
       const double cost = (double)rounds * ((double)t * nstages + 1.5);

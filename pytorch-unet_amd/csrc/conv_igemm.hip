@@ -765,7 +765,8 @@ int launch_db(const ConvParams& P, hipStream_t s) {
   int tpb = 1;
   {
     double best = 1e30;
-    for (int t = 1; t <= 16; ++t) {
+    UNETK_KNOB(tpb_max, "UNETK_CONV_TPB_MAX", 96);
+    for (int t = 1; t <= tpb_max; ++t) {
       const long wgs = ((ntiles + t - 1) / t) * Q.n_tiles;
       const long rounds = (wgs + 255) / 256;
       const double cost = (double)rounds * ((double)t * nchunks + 1.5);
@@ -1066,7 +1067,8 @@ template <typename T, int MODE, int NW = 8, int KS = 4> int launch_pw(const Conv
   int tpb = 1;
   {
     double best = 1e30;
-    for (int t = 1; t <= 16; ++t) {
+    UNETK_KNOB(tpb_max, "UNETK_CONV_TPB_MAX", 96);
+    for (int t = 1; t <= tpb_max; ++t) {
       const long wgs = ((ntiles + t - 1) / t) * Q.n_tiles;
       const long rounds = (wgs + 256 * WG_PER_CU - 1) / (256 * WG_PER_CU);
       const double cost = (double)rounds * ((double)t * niter + 1.5);
