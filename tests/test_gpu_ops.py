@@ -293,6 +293,26 @@ def test_seg_loss_fwd_bwd(dtype, ncls, empty):
     assert rel_err(_np(dl2), 0.5 * rdz) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('n,h,w', [(1, 5, 7), (3, 33, 41), (1, 1, 2)])
+def test_seg_loss_two_classes_vector_path_with_tail(dtype, n, h, w):
+    """The packed two-class forward reads four pixels per thread; pixel counts that are not multiples of four (and
+    out-of-range labels, which count for no class) must match the oracle like any other."""
+    from oracle import ops_numpy as O
+    from unetk import ops
+    z = _rand((n, h, w, 2), 83, 3.0).to(dtype)
+    g = torch.Generator().manual_seed(84)
+    mask = torch.randint(0, 2, (n, h, w), generator=g)
+    out4 = ops.seg_loss_fwd(z.cuda(), mask.cuda())
+    rloss, _ = O.seg_loss_fwd_bwd(_np(z), mask.numpy())
+    assert abs(float(out4[0]) - rloss) < 1e-5 * max(1.0, abs(rloss))
+    # the same logits as a channel slice of a wider buffer (pitch 4) take the generic kernel: same loss
+    wide = torch.zeros((n, h, w, 4), dtype=dtype)
+    wide[..., :2] = z
+    out4w = ops.seg_loss_fwd(wide.cuda()[..., :2], mask.cuda())
+    assert abs(float(out4w[0]) - float(out4[0])) < 1e-6 * max(1.0, abs(rloss))
+
+
 def test_loss_matches_reference_golden():
     """The reference-generated fixture itself (tests/golden/loss_*.npz), not just the restatement."""
     from conftest import golden
