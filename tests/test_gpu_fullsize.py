@@ -264,6 +264,17 @@ def test_batch8_1918x1280_image7_equals_the_same_image_alone(cin, cout):
         assert torch.equal(dx[i], ops.conv3x3_dgrad(dy[i:i + 1], wpd, cin)[0]), f'dgrad image {i}'
     wrot = wd.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * 9).t().contiguous()
     assert torch.equal(dx[7].float(), (_im2col(dy[7:8].float()) @ wrot).reshape(h, w, cin)), 'dgrad image 7 vs im2col'
+    # wgrad over the vertically stacked batch (8 x 1281 virtual rows): integer sums < 2^24, so the batch's gradient is
+    # EXACTLY the sum of the eight single-image gradients
+    dw = torch.empty((cout, cin, 3, 3), device='cuda')
+    ops.conv3x3_wgrad(x, dy, dw)
+    acc = torch.zeros_like(dw)
+    dw1 = torch.empty_like(dw)
+    for i in range(n):
+        ops.conv3x3_wgrad(x[i:i + 1], dy[i:i + 1], dw1)
+        acc += dw1
+    assert acc.abs().max() < 2 ** 24
+    assert torch.equal(dw, acc), 'wgrad over 8 images vs sum of single-image wgrads'
     del dy, y, yf
 
     # BatchNorm + ReLU forward apply and backward apply on the [8, 1280, 1918, cin] tensors, fixed coefficients

@@ -28,7 +28,8 @@ def _np(t):
 @pytest.mark.parametrize('n,h,w,cin,cout', [(1, 8, 32, 64, 64), (2, 16, 23, 64, 128), (3, 13, 70, 128, 64),
                                             (3, 33, 7, 64, 128), (2, 45, 18, 128, 256), (5, 40, 9, 64, 128),
                                             (2, 35, 10, 128, 64),     # ... with the operands' roles swapped
-                                            (3, 37, 11, 64, 64), (1, 70, 6, 192, 64)])   # ... its 64 x 64 variant
+                                            (3, 37, 11, 64, 64), (1, 70, 6, 192, 64),     # ... its 64 x 64 variant
+                                            (1, 33, 1, 128, 128), (2, 34, 3, 64, 64)])   # narrower than one 4-column tile
 def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
     from oracle import ops_numpy as O
     from unetk import ops
