@@ -13,7 +13,12 @@ class BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, impl, n_inputs, *tensors):
         inputs, params = tensors[:n_inputs], tensors[n_inputs:]
-        out, saved = impl.fwd(*[ops.to_nhwc(t.detach()) for t in inputs])
+        from . import blocks
+        prev, blocks.SAVING_FOR_BACKWARD = blocks.SAVING_FOR_BACKWARD, True
+        try:
+            out, saved = impl.fwd(*[ops.to_nhwc(t.detach()) for t in inputs])
+        finally:
+            blocks.SAVING_FOR_BACKWARD = prev
         ctx.impl, ctx.saved, ctx.params, ctx.n_inputs = impl, saved, params, n_inputs
         ctx.in_dtypes = [t.dtype for t in inputs]
         ctx.out_dtype = out.dtype

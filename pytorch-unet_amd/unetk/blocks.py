@@ -17,6 +17,10 @@ import torch
 from . import ops
 
 
+# set by the autograd glue while a forward runs that a backward will follow (grad mode itself is off inside
+# torch.autograd.Function.forward): eval-mode BatchNorm layers then keep their pre-BN tensor instead of fusing it away
+SAVING_FOR_BACKWARD = False
+
 # inference: fold eval-mode BatchNorm + ReLU (+ MaxPool2d) into the conv epilogue.  Tests flip it to compare the fused
 # kernels with the unfused chain (conv -> bn_relu_apply -> maxpool) on the same net.
 FUSE_EVAL_EPILOGUE = True
@@ -136,7 +140,7 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     batch_stats = _bn_uses_batch_stats(bn)
     n, h, w, _, _ = ops.nhwc_meta(x, 'conv input')
     stats = ops.new_stats(c_out, x.device) if batch_stats else None
-    if not batch_stats and FUSE_EVAL_EPILOGUE and (c_in <= 4 or dtype == torch.bfloat16):
+    if not batch_stats and FUSE_EVAL_EPILOGUE and not SAVING_FOR_BACKWARD and (c_in <= 4 or dtype == torch.bfloat16):
         # inference (evaluate.py:10, predict.py:20 call net.eval()): BatchNorm with running statistics is a per-channel
         # affine map -> folded with the ReLU into the conv epilogue, no pre-BN tensor, no second pass
         st = ops.BNState(c_out, x.device)
@@ -175,7 +179,7 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
             num_batches_tracked = bn.num_batches_tracked if update else None
         ops.bn_train_finalize(stats, n * h * w, _B, st, float(momentum or 0.0), float(bn.eps))
     else:
-        ops.bn_eval_params(bn, st, float(bn.eps))
+        ops.bn_eval_params(bn, st, float(bn.eps), for_backward=SAVING_FOR_BACKWARD)
     if head is not None and pool_out is None and ops.head_fwd_fusable(c_out, head['conv'].out_channels, dtype) \
             and head['conv'].kernel_size == (1, 1):
         hc = head['conv']
@@ -202,11 +206,12 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
     done: callback(params) invoked once this layer's parameter gradients are queued (gradient bucketing, unetk.ddp)."""
     x, y, st = saved
     c_in, c_out = conv.in_channels, conv.out_channels
-    if not _bn_uses_batch_stats(bn):
-        raise RuntimeError('backward through eval-mode BatchNorm is not implemented (the reference trains in train mode)')
+    if y is None:
+        raise RuntimeError('this forward ran outside autograd (fused inference epilogue): nothing was saved for backward')
+    frozen = not _bn_uses_batch_stats(bn)       # eval-mode BatchNorm: running statistics are constants of the graph
     dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
     dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
-    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead, sums=bn_sums)
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead, sums=bn_sums, frozen=frozen)
     dw = _grad_buf(grads, conv.weight)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)

@@ -407,11 +407,15 @@ def bn_train_finalize(stats, count, bn, state, momentum, eps):
                                         state.invstd.data_ptr(), c, stream_ptr()), 'unetk_bn_train_finalize')
 
 
-def bn_eval_params(bn, state, eps):
+def bn_eval_params(bn, state, eps, for_backward=False):
+    """for_backward: also mean / invstd of the running statistics (what the backward passes normalise with)."""
     c = state.scale.numel()
     check(fn['unetk_bn_eval_params'](_ptr(bn.weight), _ptr(bn.bias), bn.running_mean.data_ptr(),
                                      bn.running_var.data_ptr(), eps, state.scale.data_ptr(), state.shift.data_ptr(), c,
                                      stream_ptr()), 'unetk_bn_eval_params')
+    if for_backward:
+        state.mean.copy_(bn.running_mean)
+        state.invstd.copy_(torch.rsqrt(bn.running_var.float() + eps))
 
 
 def bn_relu_apply(y, state, out=None, pool_out=None):
@@ -451,8 +455,28 @@ def head_bwd_fusable(c, n_classes, dtype):
     return n_classes <= 4 and pool_bwd_fusable(c, dtype)
 
 
-def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None, sums=None):
+def _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen):
+    """sums -> dgamma, dbeta and the three coefficients of the apply pass (dy = c0*dz - c1 - c2*(y - mean)).
+    frozen: BatchNorm ran on its RUNNING statistics (module in eval mode, train.py never does this while training; a
+    fine-tuning loop with frozen statistics does): mean and invstd are constants of the graph, so the batch-statistics
+    terms vanish -- c0 = gamma*invstd = scale, c1 = c2 = 0 -- and the sums are the parameter gradients themselves."""
+    c = state.scale.numel()
+    if not frozen:
+        check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
+                                               _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+        return
+    s = sums.view(nat.STAT_REPLICAS, c, 2).sum(0)
+    if dbeta is not None:
+        dbeta.copy_(s[:, 0])
+    if dgamma is not None:
+        dgamma.copy_(s[:, 1])
+    coef.zero_()
+    coef[0].copy_(state.scale)
+
+
+def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None, sums=None, frozen=False):
     """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
+    frozen: the forward used the running statistics (see _bn_bwd_finalize).
     dpool: the layer's output also fed MaxPool2d(2) -- `dout` is then only the skip-connection gradient and the
     pooled gradient [N,H//2,W//2,C] is scattered in on the fly (no max-pool backward pass).
     dhead: (dlogits [N,H,W,n_classes], OutConv weight fp32 [n_classes, C], dw, db) -- the layer's output fed OutConv;
@@ -462,7 +486,7 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
     if sums is not None and (dpool is not None or dhead is not None):
         raise RuntimeError('bn_relu_bwd: precomputed sums only apply to the plain (no pool, no head) layer')
     if dhead is not None:
-        return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out, *dhead[2:])
+        return _bn_relu_bwd_head(dhead[0], dhead[1], y, state, gamma, dgamma, dbeta, out, *dhead[2:], frozen=frozen)
     n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
     _, _, _, _, ldy = nhwc_meta(y, 'bn saved input')
     dc = dtype_code(y.dtype)
@@ -491,8 +515,7 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
         check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
                                              state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
                                              sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
-    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
-                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+    _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen)
     if dpool is not None:
         check(fn['unetk_bn_relu_bwd_apply_pool'](dout.data_ptr(), lddo, dpool.data_ptr(), lddp, y.data_ptr(), ldy,
                                                  state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
@@ -510,7 +533,7 @@ def new_zero_doubles(n, device):
     return t if t is not None else torch.zeros(n, dtype=torch.float64, device=device)
 
 
-def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out, dw_head=None, db_head=None):
+def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out, dw_head=None, db_head=None, frozen=False):
     n, h, w, c, ldy = nhwc_meta(y, 'bn saved input')
     dn, dh, dw_, ncls, lddl = nhwc_meta(dl, 'head grad')
     if (dn, dh, dw_) != (n, h, w) or dl.dtype != y.dtype or w_head.dtype != torch.float32 or w_head.numel() != ncls * c \
@@ -535,8 +558,7 @@ def _bn_relu_bwd_head(dl, w_head, y, state, gamma, dgamma, dbeta, out, dw_head=N
     if hsums is not None:
         check(fn['unetk_conv1x1_wgrad_finalize'](hsums.data_ptr(), dw_head.data_ptr(), _ptr(db_head), c, ncls,
                                                  stream_ptr()), 'unetk_conv1x1_wgrad_finalize')
-    check(fn['unetk_bn_relu_bwd_finalize'](sums.data_ptr(), npix, _ptr(gamma), state.invstd.data_ptr(), _ptr(dgamma),
-                                           _ptr(dbeta), coef.data_ptr(), c, stream_ptr()), 'unetk_bn_relu_bwd_finalize')
+    _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen)
     check(fn['unetk_bn_relu_bwd_apply_head'](dl.data_ptr(), lddl, w_head.data_ptr(), ncls, y.data_ptr(), ldy,
                                              state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
                                              coef.data_ptr(), out.data_ptr(), ldo, npix, c, dc, stream_ptr()),

@@ -233,3 +233,54 @@ def test_fused_optimizer_state_dict_is_rmsprops_and_accumulation_is_refused():
     ta.optimizer.zero_grad()
     segmentation_loss(nets[0](img), mask).backward()                 # fine again after zero_grad()
     ta.optimizer.step()
+
+
+@pytest.mark.parametrize('ncls,bilinear', [(2, False), (5, True)])
+def test_backward_through_eval_mode_batchnorm_matches_torch(ncls, bilinear):
+    """Fine-tuning with FROZEN BatchNorm statistics (net.eval() with gradients enabled): the running statistics are
+    constants of the graph, so dz = gamma * invstd * dout * [relu mask] with no batch-statistics terms.  Torch's autograd
+    on the stock-module restatement is the reference (the reference repository itself never trains in eval mode); one
+    training-mode forward first moves the running statistics away from (0, 1)."""
+    from oracle.unet_torch import TorchUNet, segmentation_loss as ref_loss
+    from unet import UNet
+    from unetk.loss import segmentation_loss
+    shape = (2, 3, 48, 67)
+    img = torch.from_numpy(W.wave('evalbn.img', shape, 0.5, 0.5))
+    mask = torch.from_numpy(W.int_wave('evalbn.mask', (2, 48, 67), ncls))
+    ref = _closed_form(TorchUNet(3, ncls, bilinear)).train()
+    with torch.no_grad():
+        ref(img)
+    ref.eval()
+    rloss = ref_loss(ref(img), mask, ncls)
+    rloss.backward()
+
+    net = _closed_form(UNet(3, ncls, bilinear)).cuda().to(memory_format=torch.channels_last).train()
+    x = img.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        net(x)
+    net.eval()
+    logits = net(x)                                     # gradients enabled: nothing is fused away
+    loss = segmentation_loss(logits, mask.cuda())
+    loss.backward()
+    assert abs(float(loss) - float(rloss)) < 1e-4 * max(1.0, abs(float(rloss)))
+    rp = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        g, r = p.grad.float().cpu().numpy(), rp[k].grad.numpy()
+        if np.abs(r).max() == 0:
+            assert np.abs(g).max() == 0, k
+            continue
+        worst = max(worst, l2_err(g, r))
+        assert l2_err(g, r) < 1e-2, (k, l2_err(g, r))   # ReLU knife edges: see DESIGN.md section 3
+    # running statistics untouched by the eval-mode pass
+    rb = dict(ref.named_buffers())
+    for k, b in net.named_buffers():
+        if 'num_batches' in k:
+            assert int(b) == 1
+        else:
+            assert rel_err(npy(b), rb[k].numpy()) < 1e-4, k
+    # and the inference path (no autograd) still takes the fused epilogue and gives the same logits
+    with torch.no_grad():
+        fused = net(x)
+    assert rel_err(npy(fused), npy(logits)) < 1e-5
