@@ -108,6 +108,12 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
                               int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
                               void* stream);
 
+/* Gradient w.r.t. the network INPUT of that layer (autograd of unet_parts.py:16 when the image requires a gradient --
+ * the reference's train loop never does, saliency / adversarial uses do): dx fp32 [n][h][wd][c_in] (pitch lddx),
+ * dx[q][ci] = sum_{tap,co} dy[q - (tap - 1)][co] * w[co][ci][tap]; w is the UNPACKED parameter; c_out <= 512. */
+int unetk_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int lddx, int n, int h, int wd,
+                              int c_in, int c_out, int dtype, void* stream);
+
 /* ---- ConvTranspose2d(c_in -> c_out, k2, s2) + bias, fused with F.pad and the concat placement:
  * unet_parts.py:53 (aten::conv_transpose2d), :59-63 (constant_pad_nd), :67 (cat).
  * x [n,h,w,c_in]; y = channel slice [y_choff, y_choff+c_out) of the [n,hs,ws,ldy] concat buffer;

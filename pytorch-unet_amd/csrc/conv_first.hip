@@ -513,6 +513,61 @@ int first_nsplit(int ntiles, int col_tiles) {
   return ns;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient w.r.t. the INPUT IMAGE of the first layer (autograd of unet_parts.py:16 for the network input; the
+// reference's training loop never asks for it -- saliency maps / adversarial examples do):
+//   dx[q][ci] = sum_{tap, co} dy[q - (tap - 1)][co] * w[co][ci][tap]
+// c_in <= 4 outputs per pixel from 9 x c_out gradient values: a memory-bound gather (dy is read once from HBM, the
+// nine taps of neighbouring pixels hit the caches), one thread per pixel, the whole filter in LDS as [tap][co][4].
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const T* __restrict__ dy, int lddy,
+                                                               const float* __restrict__ w, float* __restrict__ dx,
+                                                               int lddx, int N, int H, int W, int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wl = reinterpret_cast<f32x4*>(smem);            // [9][Cout] x (ci 0..3, zero-padded)
+  for (int i = threadIdx.x; i < 9 * Cout; i += blockDim.x) {
+    const int tap = i / Cout, co = i - tap * Cout;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < Cin; ++ci) v[ci] = w[((size_t)co * Cin + ci) * 9 + tap];
+    wl[i] = v;
+  }
+  __syncthreads();
+  constexpr int E = ElemTraits<T>::E;
+  const long npix = (long)N * H * W;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npix; q += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(q % W);
+    const long r = q / W;
+    const int y = (int)(r % H);
+    const long img = r / H;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh) {
+      const int yy = y - (kh - 1);
+      if (yy < 0 || yy >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int xx = x - (kw - 1);
+        if (xx < 0 || xx >= W) continue;
+        const T* p = dy + ((img * H + yy) * (long)W + xx) * lddy;
+        const f32x4* wt = wl + (kh * 3 + kw) * Cout;
+        for (int c0 = 0; c0 < Cout; c0 += E) {
+          T v[E];
+          *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p + c0);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float g = to_f32(v[e]);
+            const f32x4 ww = wt[c0 + e];
+            acc[0] = fmaf(g, ww[0], acc[0]);
+            acc[1] = fmaf(g, ww[1], acc[1]);
+            acc[2] = fmaf(g, ww[2], acc[2]);
+            acc[3] = fmaf(g, ww[3], acc[3]);
+          }
+        }
+      }
+    }
+    float* o = dx + q * lddx;
+    for (int ci = 0; ci < Cin; ++ci) o[ci] = acc[ci];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -590,6 +645,27 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(P.col_tiles * 36), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, dw, P.nsplit, P.col_tiles, c_in, c_out);
+  UNETK_CHECK_LAUNCH();
+  return UNETK_OK;
+}
+
+int unetk_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int lddx, int n, int h, int wd,
+                              int c_in, int c_out, int dtype, void* stream) {
+  if (!dy || !w || !dx || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
+  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || c_out > 512 || lddx < c_in || lddy < c_out) return UNETK_ERR_SHAPE;
+  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (lddy * es) % 16) return UNETK_ERR_ALIGN;
+  const long npix = (long)n * h * wd;
+  long g = (npix + 255) / 256;
+  if (g > 4096) g = 4096;
+  const size_t lds = (size_t)9 * c_out * 16;
+  if (dtype == UNETK_BF16)
+    hipLaunchKernelGGL(conv_first_dgrad_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16*)dy, lddy, w, dx, lddx, n, h, wd, c_in, c_out);
+  else
+    hipLaunchKernelGGL(conv_first_dgrad_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const float*)dy, lddy, w, dx, lddx, n, h, wd, c_in, c_out);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -218,7 +218,7 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
         if done is not None:
             done(conv_bn_params(conv, bn))
         if need_dx:
-            raise RuntimeError('gradient w.r.t. the input image is not implemented (the reference never needs it)')
+            return ops.conv3x3_first_dgrad(dy, _f32c(conv.weight), c_in)
         return None
     ops.conv3x3_wgrad(x, dy, dw)
     if done is not None:

@@ -313,6 +313,16 @@ def conv3x3_first_wgrad(x_f32, dy, dw):
     return dw
 
 
+def conv3x3_first_dgrad(dy, w_param, c_in):
+    """Gradient w.r.t. the fp32 NHWC input image of the first layer: [N,H,W,c_in] fp32."""
+    require_cuda(dy, w_param)
+    n, h, w, c_out, lddy = nhwc_meta(dy, 'first conv dy')
+    dx = new_nhwc(n, h, w, c_in, torch.float32, dy.device)
+    check(fn['unetk_conv3x3_first_dgrad'](dy.data_ptr(), lddy, w_param.data_ptr(), dx.data_ptr(), c_in, n, h, w, c_in,
+                                          c_out, dtype_code(dy.dtype), stream_ptr()), 'unetk_conv3x3_first_dgrad')
+    return dx
+
+
 # ------------------------------------------------------------------------------------ transposed conv (+pad+cat)
 def convT2x2_fwd(x, wpk, bias, cat, choff, c_out, pad_t, pad_l):
     """Writes the up-sampled half into cat[..., choff:choff+c_out] and zeroes the F.pad border."""

@@ -57,6 +57,20 @@ def test_conv3x3_wgrad_channel_slices():
 
 # --------------------------------------------------------------------------------------- first layer
 @pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 16, 23, 3, 64), (1, 9, 40, 1, 64), (1, 8, 32, 4, 128), (1, 1, 1, 3, 64)])
+def test_first_conv_input_gradient(dtype, n, h, w, cin, cout):
+    """unetk_conv3x3_first_dgrad against the NumPy oracle's conv3x3 input gradient."""
+    from oracle import ops_numpy as O
+    from unetk import ops
+    dy = _rand((n, h, w, cout), 25).to(dtype)
+    wt = _rand((cout, cin, 3, 3), 26, 0.2)
+    dx = ops.conv3x3_first_dgrad(dy.cuda(), wt.cuda(), cin)
+    assert dx.dtype == torch.float32 and tuple(dx.shape) == (n, h, w, cin)
+    ref, _ = O.conv3x3_bwd(np.zeros((n, h, w, cin)), _np(wt), _np(dy))
+    assert rel_err(_np(dx), ref) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', BOTH)
 @pytest.mark.parametrize('n,h,w,cin', [(2, 16, 23, 3), (1, 9, 40, 1), (1, 8, 32, 4)])
 def test_first_conv_fprop(dtype, n, h, w, cin):
     from oracle import ops_numpy as O
