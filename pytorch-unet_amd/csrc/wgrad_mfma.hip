@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512) void wgrad4_bf16_kernel(Wgrad3Params P) {
 // change).  K = 32 pixels per instruction runs down a 32-ROW pixel column, so the reuse of wgrad3/4 stays: the A
 // fragment of (column c, kernel row kh) serves kw = 0, 1, 2 against the dy fragments of columns c, c-1, c-2.
 //
-//   tile     32 rows x 4 columns of output pixels x 64 ci x 128 co.  Rows are VIRTUAL rows: the images of the batch
+//   tile     32 rows x 5 columns (NCO = 64: 4) of output pixels x 64 ci x 128 co.  Rows are VIRTUAL rows: the images of the batch
 //            stacked with one all-zero row between them (H + 1 virtual rows per image).  GEMM-K of a weight gradient
 //            is the set of all pixels, so a column may run across an image boundary as long as the row between the
 //            images reads as zero in both operands (x: that IS the zero padding both neighbours need; dy: adds
@@ -610,13 +610,18 @@ __device__ __forceinline__ frag5_t tr_read8u(int addr0, int addr1, int imm) {
 // tile is 32 x 4 pixels x 128 B, stored like the x halo as two planes of 64 B per pixel (pitch 5 pixels); waves = 2
 // (32 ci) x 2 (32 co) x 2 COLUMN GROUPS: group g takes dy columns 2g, 2g+1 against halo columns 2g..2g+3 (four column
 // steps, 72 MFMAs per wave and tile) and writes its own partial-sum slab -- the split reduction adds 2 x nsplit slabs.
-template <int NCO>
+// TW: tile width in pixel columns.  The x halo's pitch of 7 pixels (odd: bank spreading) holds 5 + 2 columns as well as
+// 4 + 2, so NCO = 128 runs 32 x 5 tiles: the same 30 KiB of halo for 25 % more pixels, 180 MFMAs per wave and barrier
+// instead of 144, and every level of the 959 x 640 pyramid (W + 1 = 960, 480, 240, 120, 60) is a whole number of tiles.
+template <int NCO, int TW>
 __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   constexpr bool WIDE = NCO == 128;
-  constexpr int NSTEP = WIDE ? 6 : 4;                    // halo columns a wave walks per tile
-  constexpr int NBC = WIDE ? 4 : 2;                      // dy columns a wave holds (ring)
+  static_assert(WIDE ? (TW == 4 || TW == 5) : TW == 4, "tile widths the LDS layouts are made for");
+  constexpr int NSTEP = WIDE ? TW + 2 : 4;               // halo columns a wave walks per tile
+  constexpr int NBC = WIDE ? TW : 2;                     // dy columns a wave holds
+  constexpr int NRING = WIDE ? (TW == 4 ? 4 : 5) : 2;    // ... in a ring of this many fragment pairs
   constexpr int B_PLANE = 32 * 5 * 64;                   // NCO = 64: bytes per co plane
-  constexpr int B_PIECES = WIDE ? W5_B_PIECES : 2 * B_PLANE / 1024;   // 32 / 20
+  constexpr int B_PIECES = WIDE ? 32 * TW * 256 / 1024 : 2 * B_PLANE / 1024;   // 32 (40) / 20
   constexpr int PIECES = W5_A_PIECES + B_PIECES;         // 62 / 50
   constexpr int BUF = PIECES * 1024;
   constexpr int SLOTS = (PIECES + 7) / 8;                // 8 / 7
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
     for (int co = 0; co < 2; ++co) {
       if constexpr (WIDE)
-        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 4) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
+        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * TW) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
       else     // co plane = immediate (addrB[1] unused)
         addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 5 + 2 * grp) * 64 + (((wj ^ ((k >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
     }
@@ -672,12 +677,13 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
       hr = px / W5_AP;
       hc = px - hr * W5_AP;
       piece = 4 * ((sl >> 1) ^ ((hr >> 3) & 1)) + 2 * plane + (sl & 1);
-      if (hc >= 6 || hr >= 34) hr = 255;                     // pitch padding / beyond the planes: never valid
+      if (hc >= TW + 2 || hr >= 34) hr = 255;                // pitch padding / beyond the planes: never valid
     } else if constexpr (WIDE) {
       const int p = (fi - W5_A_PIECES) * 4 + (lane >> 4), ls = lane & 15;
-      hr = (p >> 2) + 1;
-      hc = (p & 3) + 1;
-      piece = ls ^ swz5b(p >> 2);
+      const int r = p / TW;
+      hr = r + 1;
+      hc = p - r * TW + 1;
+      piece = ls ^ swz5b(r);
     } else {
       const int s = (fi - W5_A_PIECES) * 64 + lane;
       const int plane = s >= B_PLANE / 16 ? 1 : 0;
@@ -689,12 +695,12 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
       piece = 4 * ((sl >> 1) ^ ((r >> 3) & 1)) + 2 * plane + (sl & 1);
     }
   };
-  unsigned hc_pack = 0;                                        // 4 bits per slot: hc
+  unsigned hc_pack = 0;                                        // 3 bits per slot: hc (0..6)
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) {
     int hr, hc, piece;
     slot_geom(q, lane, hr, hc, piece);
-    hc_pack |= (unsigned)hc << (4 * q);
+    hc_pack |= (unsigned)(hc & 7) << (3 * q);
   }
 
   f32x4 acc[9][2][2];                              // [tap][ci half][co half]
@@ -761,8 +767,8 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
     const bool is_a = fi < W5_A_PIECES;                         // wave-uniform
     unsigned hp = hc_pack;
     asm volatile("" : "+v"(hp));     // opaque: otherwise the eight fields are extracted once, kept and spilled
-    const int xx = (int)((hp >> (4 * q)) & 15u) - 1 + 4 * s_tx;
-    const unsigned step = (unsigned)(4 * s_tx) * ((unsigned)(is_a ? P.lda : P.ldb) * 2u);   // scalar
+    const int xx = (int)((hp >> (3 * q)) & 7u) - 1 + TW * s_tx;
+    const unsigned step = (unsigned)(TW * s_tx) * ((unsigned)(is_a ? P.lda : P.ldb) * 2u);   // scalar
     const unsigned off = ((unsigned)xx < (unsigned)P.W) ? voff_q + step : 0x80000000u;
     unetk_u32x4 d = is_a ? dsc_a : dsc_b;
     d[2] = live ? d[2] : 0u;
@@ -776,12 +782,12 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   int cur = 0;
 
-  frag5_t fa[3][2], fb[NBC][2];
+  frag5_t fa[3][2], fb[NRING][2];
   auto read_a = [&](int kh, int ci, int cc) {                  // A fragment (kh, ci half) of halo column cc
     fa[kh][ci] = tr_read8u(addrA[kh][0], addrA[kh][1], ci * W5_A_PLANE + cc * 64);
   };
   auto read_b = [&](int co, int c) {                           // dy fragment (co half) of column c
-    if constexpr (WIDE) fb[c & 3][co] = tr_read8u(addrB[co][0], addrB[co][1], c * 256);
+    if constexpr (WIDE) fb[c % NRING][co] = tr_read8u(addrB[co][0], addrB[co][1], c * 256);
     else fb[c & 1][co] = tr_read8u(addrB[0][0], addrB[0][1], co * B_PLANE + c * 64);
   };
 #pragma unroll
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
               for (int co = 0; co < 2; ++co)
                 acc[kh * 3 + kw][ci][co] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, fa[kh][ci]), __builtin_bit_cast(bf16x8, fb[bl & (NBC - 1)][co]),
+                    __builtin_bit_cast(bf16x8, fa[kh][ci]), __builtin_bit_cast(bf16x8, fb[bl % NRING][co]),
                     acc[kh * 3 + kw][ci][co], 0, 0, 0);
             }
           }
@@ -1379,8 +1385,8 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
     const size_t lds = 2 * (50 * 1024) + 7 * 512 * 4;
-    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64>), lds);
-    hipLaunchKernelGGL(wgrad5_bf16_kernel<64>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 4>), lds);
+    hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                        (hipStream_t)stream, P);
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, 2 * P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
@@ -1397,14 +1403,24 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     } else {
       P.a = (const bf16*)dy; P.b = (const bf16*)x; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
     }
-    P.tiles_x = host_cdiv(w, 4);
+    UNETK_KNOB(tw5, "UNETK_WGRAD_TW5", 1);     // 0: A/B against 32 x 4 tiles
+    P.tiles_x = host_cdiv(w, tw5 ? 5 : 4);
     P.ntiles = host_cdiv((long)n * (h + 1), 32) * P.tiles_x;
     P.row_tiles = P.Ca / 64; P.col_tiles = P.Cb / 128;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
-    const size_t lds = 2 * W5_BUF + W5_SLOTS * 512 * 4;
-    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128>), lds);
-    hipLaunchKernelGGL(wgrad5_bf16_kernel<128>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
-                       (hipStream_t)stream, P);
+    if (tw5) {
+      const size_t lds = 2 * ((W5_A_PIECES + 40) * 1024) + 9 * 512 * 4;
+      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128, 5>), lds);
+      hipLaunchKernelGGL((wgrad5_bf16_kernel<128, 5>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                         (hipStream_t)stream, P);
+    } else {
+#ifdef UNETK_TUNING      // A/B builds only: the 32 x 4 form is not compiled into the shipped library
+      const size_t lds = 2 * W5_BUF + W5_SLOTS * 512 * 4;
+      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128, 4>), lds);
+      hipLaunchKernelGGL((wgrad5_bf16_kernel<128, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                         (hipStream_t)stream, P);
+#endif
+    }
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, P.Ca, P.Cb, accumulate, (hipStream_t)stream, w5_swapped);
     UNETK_CHECK_LAUNCH();
