@@ -607,24 +607,32 @@ __device__ __forceinline__ frag5_t tr_read8u(int addr0, int addr1, int imm) {
 }
 
 // NCO = 128: as described above.  NCO = 64 (c_out and c_in both not multiples of 128, i.e. the 64 -> 64 layers): the dy
-// tile is 32 x 4 pixels x 128 B, stored like the x halo as two planes of 64 B per pixel (pitch 5 pixels); waves = 2
-// (32 ci) x 2 (32 co) x 2 COLUMN GROUPS: group g takes dy columns 2g, 2g+1 against halo columns 2g..2g+3 (four column
-// steps, 72 MFMAs per wave and tile) and writes its own partial-sum slab -- the split reduction adds 2 x nsplit slabs.
+// tile is 32 x 6 pixels x 128 B, stored like the x halo as two planes of 64 B per pixel (pitch 7 pixels; x halo pitch 9);
+// waves = 2 (32 ci) x 2 (32 co) x 2 COLUMN GROUPS: group g takes dy columns 3g..3g+2 against halo columns 3g..3g+4 (five
+// column steps, 108 MFMAs per wave and tile for 36 fragment KiB; 32 x 4 tiles with two columns per group: 72 MFMAs for
+// 28 KiB -- this variant sits on the LDS port, 0.76 -> 0.72 ms at 64 -> 64) and writes its own partial-sum slab -- the
+// split reduction adds 2 x nsplit slabs.
 // TW: tile width in pixel columns.  The x halo's pitch of 7 pixels (odd: bank spreading) holds 5 + 2 columns as well as
 // 4 + 2, so NCO = 128 runs 32 x 5 tiles: the same 30 KiB of halo for 25 % more pixels, 180 MFMAs per wave and barrier
 // instead of 144, and every level of the 959 x 640 pyramid (W + 1 = 960, 480, 240, 120, 60) is a whole number of tiles.
 template <int NCO, int TW>
 __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   constexpr bool WIDE = NCO == 128;
-  static_assert(WIDE ? (TW == 4 || TW == 5) : TW == 4, "tile widths the LDS layouts are made for");
-  constexpr int NSTEP = WIDE ? TW + 2 : 4;               // halo columns a wave walks per tile
-  constexpr int NBC = WIDE ? TW : 2;                     // dy columns a wave holds
-  constexpr int NRING = WIDE ? (TW == 4 ? 4 : 5) : 2;    // ... in a ring of this many fragment pairs
-  constexpr int B_PLANE = 32 * 5 * 64;                   // NCO = 64: bytes per co plane
-  constexpr int B_PIECES = WIDE ? 32 * TW * 256 / 1024 : 2 * B_PLANE / 1024;   // 32 (40) / 20
-  constexpr int PIECES = W5_A_PIECES + B_PIECES;         // 62 / 50
+  static_assert(WIDE ? (TW == 4 || TW == 5) : (TW == 4 || TW == 6), "tile widths the LDS layouts are made for");
+  constexpr int CG = WIDE ? TW : TW / 2;                 // dy columns per wave (NCO = 64: per column group)
+  constexpr int NSTEP = CG + 2;                          // halo columns a wave walks per tile
+  constexpr int NBC = CG;                                // dy columns a wave holds
+  constexpr int NRING = CG == 4 ? 4 : CG;                // ... in a ring of this many fragment pairs (2, 3, 4, 5)
+  constexpr int AP = (TW + 2) | 1;                       // x halo pitch in pixels: odd (bank spreading), 7 or 9
+  constexpr int A_PLANE = 34 * AP * 64;                  // bytes per ci plane
+  constexpr int A_SLOTS = 2 * A_PLANE / 16;
+  constexpr int A_PIECES = (A_SLOTS + 63) / 64;          // 30 / 39
+  constexpr int BP = TW | 1;                             // NCO = 64: dy pitch in pixels (odd), 5 or 7
+  constexpr int B_PLANE = 32 * BP * 64;                  // NCO = 64: bytes per co plane
+  constexpr int B_PIECES = WIDE ? 32 * TW * 256 / 1024 : 2 * B_PLANE / 1024;   // 32 (40) / 20 (28)
+  constexpr int PIECES = A_PIECES + B_PIECES;            // 62 (70) / 50 (67)
   constexpr int BUF = PIECES * 1024;
-  constexpr int SLOTS = (PIECES + 7) / 8;                // 8 / 7
+  constexpr int SLOTS = (PIECES + 7) / 8;                // 8 (9) / 7 (9)
   // (NCO = 64 with THREE buffers and two tiles of DMA look-ahead ran exactly as fast as with two -- 0.752 vs 0.755 ms at
   // 64 -> 64, 16 x 640 x 959: that variant is bound by the LDS port (28 fragment KiB per 72 MFMAs), not by latency)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -653,14 +661,14 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int row = kh + k;
-      addrA[kh][rd] = (int)lds0 + (row * W5_AP + 2 * grp) * 64 + (((wi ^ ((row >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
+      addrA[kh][rd] = (int)lds0 + (row * AP + CG * grp) * 64 + (((wi ^ ((row >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
     }
 #pragma unroll
     for (int co = 0; co < 2; ++co) {
       if constexpr (WIDE)
-        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * TW) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
+        addrB[co][rd] = (int)lds0 + A_PIECES * 1024 + (k * TW) * 256 + (((wj * 4 + 2 * co + (pp >> 1)) ^ swz5b(k)) << 4) + sub;
       else     // co plane = immediate (addrB[1] unused)
-        addrB[co][rd] = (int)lds0 + W5_A_PIECES * 1024 + (k * 5 + 2 * grp) * 64 + (((wj ^ ((k >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
+        addrB[co][rd] = (int)lds0 + A_PIECES * 1024 + (k * BP + CG * grp) * 64 + (((wj ^ ((k >> 3) & 1)) * 2 + (pp >> 1)) << 4) + sub;
     }
   }
 
@@ -669,28 +677,28 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   //      0 = tile column - 1) and the logical 16-byte piece of the pixel
   auto slot_geom = [&](int q, int lane, int& hr, int& hc, int& piece) {
     const int fi = min(q * 8 + wid, PIECES - 1);
-    if (fi < W5_A_PIECES) {
+    if (fi < A_PIECES) {
       const int s = fi * 64 + lane;
-      const int plane = s >= W5_A_SLOTS / 2 ? 1 : 0;
-      const int sp = s - plane * (W5_A_SLOTS / 2);
+      const int plane = s >= A_SLOTS / 2 ? 1 : 0;
+      const int sp = s - plane * (A_SLOTS / 2);
       const int px = sp >> 2, sl = sp & 3;
-      hr = px / W5_AP;
-      hc = px - hr * W5_AP;
+      hr = px / AP;
+      hc = px - hr * AP;
       piece = 4 * ((sl >> 1) ^ ((hr >> 3) & 1)) + 2 * plane + (sl & 1);
       if (hc >= TW + 2 || hr >= 34) hr = 255;                // pitch padding / beyond the planes: never valid
     } else if constexpr (WIDE) {
-      const int p = (fi - W5_A_PIECES) * 4 + (lane >> 4), ls = lane & 15;
+      const int p = (fi - A_PIECES) * 4 + (lane >> 4), ls = lane & 15;
       const int r = p / TW;
       hr = r + 1;
       hc = p - r * TW + 1;
       piece = ls ^ swz5b(r);
     } else {
-      const int s = (fi - W5_A_PIECES) * 64 + lane;
+      const int s = (fi - A_PIECES) * 64 + lane;
       const int plane = s >= B_PLANE / 16 ? 1 : 0;
       const int sp = s - plane * (B_PLANE / 16);
       const int px = sp >> 2, sl = sp & 3;
-      const int r = px / 5, c = px - r * 5;
-      hr = c < 4 ? r + 1 : 255;                              // pitch padding: never valid
+      const int r = px / BP, c = px - r * BP;
+      hr = c < TW ? r + 1 : 255;                             // pitch padding: never valid
       hc = c + 1;
       piece = 4 * ((sl >> 1) ^ ((r >> 3) & 1)) + 2 * plane + (sl & 1);
     }
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
     for (int q = 0; q < SLOTS; ++q) {
       int hr, hc, piece;
       slot_geom(q, lane_o, hr, hc, piece);
-      const bool is_a = min(q * 8 + wid, PIECES - 1) < W5_A_PIECES;
+      const bool is_a = min(q * 8 + wid, PIECES - 1) < A_PIECES;
       int yl = s_yb + hr - 1;
       const bool wrap = yl >= VH && hr != 255;
       yl -= wrap ? VH : 0;
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   };
   auto issue_piece = [&](int q, unsigned voff_q, unsigned buf, bool live) {     // branch-free, 5 VALU
     const int fi = min(q * 8 + wid, PIECES - 1);
-    const bool is_a = fi < W5_A_PIECES;                         // wave-uniform
+    const bool is_a = fi < A_PIECES;                            // wave-uniform
     unsigned hp = hc_pack;
     asm volatile("" : "+v"(hp));     // opaque: otherwise the eight fields are extracted once, kept and spilled
     const int xx = (int)((hp >> (3 * q)) & 7u) - 1 + TW * s_tx;
@@ -784,11 +792,11 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
 
   frag5_t fa[3][2], fb[NRING][2];
   auto read_a = [&](int kh, int ci, int cc) {                  // A fragment (kh, ci half) of halo column cc
-    fa[kh][ci] = tr_read8u(addrA[kh][0], addrA[kh][1], ci * W5_A_PLANE + cc * 64);
+    fa[kh][ci] = tr_read8u(addrA[kh][0], addrA[kh][1], ci * A_PLANE + cc * 64);
   };
   auto read_b = [&](int co, int c) {                           // dy fragment (co half) of column c
     if constexpr (WIDE) fb[c % NRING][co] = tr_read8u(addrB[co][0], addrB[co][1], c * 256);
-    else fb[c & 1][co] = tr_read8u(addrB[0][0], addrB[0][1], co * B_PLANE + c * 64);
+    else fb[c % NRING][co] = tr_read8u(addrB[0][0], addrB[0][1], co * B_PLANE + c * 64);
   };
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
@@ -1380,14 +1388,24 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.slab = (float*)workspace;
     P.N = n; P.H = h; P.W = w;
     P.a = (const bf16*)x; P.b = (const bf16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
-    P.tiles_x = host_cdiv(w, 4);
+    UNETK_KNOB(tw6, "UNETK_WGRAD_TW6", 1);     // 0: A/B against 32 x 4 tiles (two columns per group)
+    P.tiles_x = host_cdiv(w, tw6 ? 6 : 4);
     P.ntiles = host_cdiv((long)n * (h + 1), 32) * P.tiles_x;
     P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
-    const size_t lds = 2 * (50 * 1024) + 7 * 512 * 4;
-    UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 4>), lds);
-    hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
-                       (hipStream_t)stream, P);
+    if (tw6) {      // 32 x 6 tiles, three dy columns per group: 36 fragment KiB per 108 MFMAs instead of 28 per 72
+      const size_t lds = 2 * ((39 + 28) * 1024) + 9 * 512 * 4;
+      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 6>), lds);
+      hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 6>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                         (hipStream_t)stream, P);
+    } else {
+#ifdef UNETK_TUNING
+      const size_t lds = 2 * (50 * 1024) + 7 * 512 * 4;
+      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 4>), lds);
+      hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+                         (hipStream_t)stream, P);
+#endif
+    }
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, 2 * P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
