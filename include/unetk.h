@@ -11,7 +11,8 @@
  *   - activations are NHWC ("channels_last"): element (n,y,x,c) of a tensor with pixel pitch
  *     `ld` lives at ((n*H + y)*W + x)*ld + c.  `ld` >= C lets a tensor be a channel slice of a
  *     wider buffer (the decoder's concat buffer, unet_parts.py:67, is never materialised by a copy).
- *   - dtype: UNETK_BF16 (bf16 storage, fp32 accumulate) or UNETK_F32 (exact fp32 MFMA).
+ *   - dtype: UNETK_BF16 / UNETK_F16 (16-bit storage, fp32 accumulate; the same kernels over the element type) or
+ *     UNETK_F32 (exact fp32 MFMA).
  *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and
  *     return 0 or a negative UNETK_ERR_* code; no exceptions cross the ABI.
  */
@@ -24,6 +25,7 @@ extern "C" {
 
 #define UNETK_BF16 0
 #define UNETK_F32 1
+#define UNETK_F16 2
 
 #define UNETK_OK 0
 #define UNETK_ERR_SHAPE (-1)   /* unsupported / inconsistent shape, pitch or channel count */

@@ -66,20 +66,24 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
   }
 }
 
-template <int NB16> __device__ __forceinline__ void store_adjacent(bf16* p, const float (&v)[NB16]) {
+template <typename H, int NB16> __device__ __forceinline__ void store_adjacent(H* p, const float (&v)[NB16]) {
+  typedef typename H16<H>::x8 h8;
+  typedef typename H16<H>::x4 h4;
   if constexpr (NB16 == 8) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    h8 o = {(H)v[0], (H)v[1], (H)v[2], (H)v[3], (H)v[4], (H)v[5], (H)v[6], (H)v[7]};
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), reinterpret_cast<u32x4*>(p));
   } else {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    h4 o = {(H)v[0], (H)v[1], (H)v[2], (H)v[3]};
     __builtin_nontemporal_store(__builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(p));
   }
 }
 
-template <int NB16, bool AFF, bool WRES>
+template <typename H, int NB16, bool AFF, bool WRES>
 __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
+  typedef typename H16<H>::x2 h2;
+  typedef typename H16<H>::x8 h8;
   constexpr int NW = 8, MB = 2, TR = MB * NW, HP = 34, S = 64, NP = 4, TAPS = 9;
   constexpr int NPIX = (TR + 2) * HP;
   constexpr int IN_INSTR = (NPIX * NP + 63) / 64;            // 39 one-KiB DMA pieces
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
     const unsigned long long xa =
-        (unsigned long long)(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+        (unsigned long long)(reinterpret_cast<const H*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
     xdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)xa);
     xdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
     xdesc[2] = img_bytes;
@@ -323,8 +327,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
 #pragma unroll
             for (int cb = 0; cb < NB16; ++cb) {
               const f32x4v c_in = (FIRSTC && st == 0 && s == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
-              acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), c_in, 0, 0, 0);
+              acc[mb][ps][cb] =
+                  H16<H>::mfma16(__builtin_bit_cast(h8, fa[mb][ps]), __builtin_bit_cast(h8, fb[cb]), c_in);
               if (ag == 2 * MB - 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + wb + (un * NB16 + cb) * 1024);
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
     // ---- epilogue of this tile: a lane holds, per (row mb, pixel set ps), 4 consecutive pixels x NB16 adjacent channels
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
-    bf16* yimg = reinterpret_cast<bf16*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+    H* yimg = reinterpret_cast<H*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
     const int xg = g4 == 1 ? 16 : g4 == 2 ? 24 : g4 == 3 ? 8 : 0;     // pixel of C row 4*g4 within the 32-pixel row
     const int xl = x0 + xg;
     const int lane_off = xg * P.ldy + ch0;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
       // 2x2 window is four registers of one lane.  max commutes with the (monotone) rounding of the store.
       if (P.pool != nullptr) {
         const int yy = y0 + MB * wid;                      // even; the window needs row yy + 1 too
-        bf16* pimg = reinterpret_cast<bf16*>(P.pool) + (size_t)img * (P.H / 2) * (P.W / 2) * P.ldp;
+        H* pimg = reinterpret_cast<H*>(P.pool) + (size_t)img * (P.H / 2) * (P.W / 2) * P.ldp;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
                 const float d = fmaxf(fmaf(acc[1][ps][cb][i + 1], asc[cb], ash[cb]), 0.f);
                 pv[cb] = fmaxf(fmaxf(a, b), fmaxf(c, d));
               }
-              store_adjacent<NB16>(pimg + ((size_t)(yy >> 1) * (P.W / 2) + (xx >> 1)) * P.ldp + ch0, pv);
+              store_adjacent<H, NB16>(pimg + ((size_t)(yy >> 1) * (P.W / 2) + (xx >> 1)) * P.ldp + ch0, pv);
             }
           }
       }
@@ -401,11 +405,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
       if ((y0 + TR <= P.H) && (x0 + 32 <= P.W)) {
         auto fast = [&](auto stats_c) {
           constexpr bool ST = decltype(stats_c)::value;
-          const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+          const h2 one2 = {(H)1.0f, (H)1.0f};
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
             const int yy = y0 + MB * wid + mb;
-            bf16* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy + lane_off;
+            H* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy + lane_off;
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
@@ -413,15 +417,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
                 unsigned pk[NB16];
 #pragma unroll
                 for (int cb = 0; cb < NB16; ++cb) {
-                  const bf16x2 y2 = {(bf16)acc[mb][ps][cb][i], (bf16)acc[mb][ps][cb][i + 1]};
+                  const h2 y2 = {(H)acc[mb][ps][cb][i], (H)acc[mb][ps][cb][i + 1]};
                   pk[cb] = __builtin_bit_cast(unsigned, y2);
                   if (!UNETK_K32_FIRSTC) acc[mb][ps][cb][i] = acc[mb][ps][cb][i + 1] = 0.f;
                   if constexpr (ST && !LDSSTATS) {    // straight into the workgroup-long sums (fp32, as the 64-channel kernel)
-                    tsum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, tsum[cb], false);
-                    tsq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, tsq[cb], false);
+                    tsum[cb] = H16<H>::dot2(y2, one2, tsum[cb]);
+                    tsq[cb] = H16<H>::dot2(y2, y2, tsq[cb]);
                   } else if constexpr (ST) {
-                    ssum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, ssum[cb], false);
-                    ssq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, ssq[cb], false);
+                    ssum[cb] = H16<H>::dot2(y2, one2, ssum[cb]);
+                    ssq[cb] = H16<H>::dot2(y2, y2, ssq[cb]);
                   }
                 }
                 typedef __attribute__((ext_vector_type(NB16 / 2))) unsigned uvec;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
     for (int mb = 0; mb < MB; ++mb) {
       if (done) break;
       const int yy = y0 + MB * wid + mb;
-      bf16* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;   // 64-bit arithmetic once per row (wave-uniform)
+      H* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;   // 64-bit arithmetic once per row (wave-uniform)
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps)
 #pragma unroll
@@ -460,13 +464,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
               if constexpr (AFF) {
                 v[cb] = fmaxf(fmaf(acc[mb][ps][cb][i], asc[cb], ash[cb]), 0.f);
               } else {
-                const float f = to_f32(from_f32<bf16>(acc[mb][ps][cb][i]));   // statistics of the value as stored
+                const float f = to_f32(from_f32<H>(acc[mb][ps][cb][i]));   // statistics of the value as stored
                 v[cb] = f;
                 ssum[cb] += f;
                 ssq[cb] += f * f;
               }
             }
-            store_adjacent<NB16>(rowp + ri * P.ldy + lane_off, v);
+            store_adjacent<H, NB16>(rowp + ri * P.ldy + lane_off, v);
           }
           if (!UNETK_K32_FIRSTC) {
 #pragma unroll
@@ -542,8 +546,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
 // produced this tensor (ConvParams::bn_z): that layer's z at the tile's pixels is fetched during the tile's LAST stage
 // -- into the registers the packed previous tile occupied until its stores went out in the first stage -- and the
 // masked sums are formed at the hand-over from the rounded values.
-template <bool WRES, int EPI>
+template <typename H, bool WRES, int EPI>
 __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
+  typedef typename H16<H>::x2 h2;
+  typedef typename H16<H>::x8 h8;
   constexpr bool STATS = EPI == 1, BNR = EPI == 2;
   constexpr int NB16 = 4, NW = 8, MB = 2, TR = MB * NW, HP = 34, NP = 4, TAPS = 9;
   constexpr int NPIX = (TR + 2) * HP;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
     const unsigned long long xa =
-        (unsigned long long)(reinterpret_cast<const bf16*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
+        (unsigned long long)(reinterpret_cast<const H*>(P.x) + (size_t)img * P.H * P.W * P.ldx + P.xoff);
     xdesc[0] = __builtin_amdgcn_readfirstlane((unsigned)xa);
     xdesc[1] = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32) & 0xffffu);
     xdesc[2] = img_bytes;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       for (int cb = 0; cb < NB16; ++cb) pk[mb][ps][cb][0] = pk[mb][ps][cb][1] = 0u;
   // where the pending stores go: row bases (wave-uniform), first pixel column of this lane, and the column limit per
   // row (0 = nothing pending / row outside the image)
-  const bf16* st_row[MB] = {nullptr, nullptr};
+  const H* st_row[MB] = {nullptr, nullptr};
   int st_wlim[MB] = {0, 0};
   int st_xl = 0;
   bool st_all16 = false;                                      // every pending store has at least one lane to write
@@ -683,14 +689,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   // (pixels outside the image were zeroed when the tile was packed; with nothing pending pk is all zero)
   auto emit_stats = [&](int g, int cb0 = 0, int cb1 = NB16) {
     const int mb = g >> 1, ps = g & 1;
-    const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+    const h2 one2 = {(H)1.0f, (H)1.0f};
 #pragma unroll
     for (int cb = cb0; cb < cb1; ++cb)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const bf16x2 y2 = __builtin_bit_cast(bf16x2, pk[mb][ps][cb][e]);
-        tsum[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, tsum[cb], false);
-        tsq[cb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, tsq[cb], false);
+        const h2 y2 = __builtin_bit_cast(h2, pk[mb][ps][cb][e]);
+        tsum[cb] = H16<H>::dot2(y2, one2, tsum[cb]);
+        tsq[cb] = H16<H>::dot2(y2, y2, tsq[cb]);
       }
   };
 
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   auto fetch_z = [&](int tile) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
-    const char* zimg = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(P.bn_z) + (size_t)img * P.H * P.W * P.ld_bnz);
+    const char* zimg = reinterpret_cast<const char*>(reinterpret_cast<const H*>(P.bn_z) + (size_t)img * P.H * P.W * P.ld_bnz);
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -806,8 +812,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
         for (int cb = 0; cb < NB16; ++cb) {
           const f32x4v c_in = (FIRST && t == 0) ? f32x4v{0.f, 0.f, 0.f, 0.f} : acc[mb][ps][cb];
-          acc[mb][ps][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8, fa[mb][ps]), __builtin_bit_cast(bf16x8, fb[cb]), c_in, 0, 0, 0);
+          acc[mb][ps][cb] = H16<H>::mfma16(__builtin_bit_cast(h8, fa[mb][ps]), __builtin_bit_cast(h8, fb[cb]), c_in);
           if (ag == 2 * MB - 1 && !(UNETK_K32_ABL & 32)) {
             __builtin_amdgcn_sched_barrier(0);
             fb[cb] = *reinterpret_cast<const AS3 frag_t*>(lds3 + wb + (tn * NB16 + cb) * 1024);
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     // ---- hand the tile over: round, statistics, remember where it goes.  Its stores ride under the next tile.
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
-    const bf16* yimg = reinterpret_cast<const bf16*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
+    const H* yimg = reinterpret_cast<const H*>(P.y) + (size_t)img * P.H * P.W * P.ldy + P.yoff;
     st_xl = x0 + xg;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = (st_xl + 4 * ps + i < st_wlim[mb]) ? a[i] : 0.f;
           }
-          bf16x2 lo = {(bf16)a[0], (bf16)a[1]}, hi = {(bf16)a[2], (bf16)a[3]};
+          h2 lo = {(H)a[0], (H)a[1]}, hi = {(H)a[2], (H)a[3]};
           rnd[cb][0] = __builtin_bit_cast(unsigned, lo);
           rnd[cb][1] = __builtin_bit_cast(unsigned, hi);
         }
@@ -902,8 +907,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
 #pragma unroll
             for (int cb = 0; cb < NB16; ++cb) {
               const unsigned zw = zr[mb][ps][i][cb >> 1], dw = rnd[cb][i >> 1];
-              const float z = __uint_as_float((cb & 1) ? (zw & 0xffff0000u) : (zw << 16));
-              const float f = __uint_as_float((i & 1) ? (dw & 0xffff0000u) : (dw << 16));
+              const float z = (cb & 1) ? H16<H>::hi(zw) : H16<H>::lo(zw);
+              const float f = (i & 1) ? H16<H>::hi(dw) : H16<H>::lo(dw);
               const float dz = (inside && fmaf(z, bsc[cb], bsh[cb]) > 0.f) ? f : 0.f;
               tsum[cb] += dz;
               tsq[cb] = fmaf(dz, z - bmu[cb], tsq[cb]);
@@ -952,9 +957,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   }
 }
 
-template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t s) {
+template <typename H, bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t s) {
   constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024) + (EPI == 2 ? 1024 : 0);
-  UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<WRES, EPI>), lds);
+  UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<H, WRES, EPI>), lds);
   ConvParams Q = P;
   Q.tiles_x = host_cdiv(P.W, 32);
   Q.tiles_y = host_cdiv(P.H, 16);
@@ -979,14 +984,14 @@ template <bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t
   Q.tpb = tpb;
   const long nblk = (ntiles + tpb - 1) / tpb;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3x3_k32n64_kernel<WRES, EPI>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
+  hipLaunchKernelGGL((conv3x3_k32n64_kernel<H, WRES, EPI>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
 
-template <int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hipStream_t s) {
+template <typename H, int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hipStream_t s) {
   constexpr size_t lds = 2 * (39 * 1024) + 2 * ((NB16 == 8 ? 5 : 9) * NB16 * 1024) + 2 * 16 * NB16 * sizeof(float);
-  UNETK_ALLOW_LDS((conv3x3_k32_kernel<NB16, AFF, WRES>), lds);
+  UNETK_ALLOW_LDS((conv3x3_k32_kernel<H, NB16, AFF, WRES>), lds);
   ConvParams Q = P;
   Q.tiles_x = host_cdiv(P.W, 32);
   Q.tiles_y = host_cdiv(P.H, 16);
@@ -1015,35 +1020,40 @@ template <int NB16, bool AFF, bool WRES> int launch_k32(const ConvParams& P, hip
   Q.dbg = 0;
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7fffffffL) return UNETK_ERR_SHAPE;
-  hipLaunchKernelGGL((conv3x3_k32_kernel<NB16, AFF, WRES>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
+  hipLaunchKernelGGL((conv3x3_k32_kernel<H, NB16, AFF, WRES>), dim3((unsigned)nblk), dim3(512), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
 
-}  // namespace
-
-int unetk_internal_conv3x3_k32(const void* params, void* stream) {
-  const ConvParams& P = *static_cast<const ConvParams*>(params);
-  hipStream_t s = (hipStream_t)stream;
+template <typename H> int dispatch_k32(const ConvParams& P, hipStream_t s) {
   if (P.Cin % 32 != 0 || P.Cout % 64 != 0) return UNETK_ERR_SHAPE;
   const int nb16 = conv3_k32_nb16(P.Cout);
   const bool aff = P.aff_scale != nullptr;
   const bool bnr = P.bn_z != nullptr;
   if (nb16 == 8) {
     if (bnr) return UNETK_ERR_UNFUSED;
-    return aff ? launch_k32<8, true, false>(P, s) : launch_k32<8, false, false>(P, s);
+    return aff ? launch_k32<H, 8, true, false>(P, s) : launch_k32<H, 8, false, false>(P, s);
   }
   const bool wres = P.Cin <= 64;                            // <= 2 weight stages: resident in the two buffers
   const bool nopipe = conv3_k32_nopipe();
   if (!aff && P.Cout == 64 && !nopipe) {
     if (bnr) {                                              // the z fetch needs a stage of its own behind the first
       if (P.Cin < 64) return UNETK_ERR_UNFUSED;
-      return wres ? launch_k32n64<true, 2>(P, s) : launch_k32n64<false, 2>(P, s);
+      return wres ? launch_k32n64<H, true, 2>(P, s) : launch_k32n64<H, false, 2>(P, s);
     }
-    if (P.stats != nullptr) return wres ? launch_k32n64<true, 1>(P, s) : launch_k32n64<false, 1>(P, s);
-    return wres ? launch_k32n64<true, 0>(P, s) : launch_k32n64<false, 0>(P, s);
+    if (P.stats != nullptr) return wres ? launch_k32n64<H, true, 1>(P, s) : launch_k32n64<H, false, 1>(P, s);
+    return wres ? launch_k32n64<H, true, 0>(P, s) : launch_k32n64<H, false, 0>(P, s);
   }
   if (bnr) return UNETK_ERR_UNFUSED;
-  if (aff) return wres ? launch_k32<4, true, true>(P, s) : launch_k32<4, true, false>(P, s);
-  return wres ? launch_k32<4, false, true>(P, s) : launch_k32<4, false, false>(P, s);
+  if (aff) return wres ? launch_k32<H, 4, true, true>(P, s) : launch_k32<H, 4, true, false>(P, s);
+  return wres ? launch_k32<H, 4, false, true>(P, s) : launch_k32<H, 4, false, false>(P, s);
+}
+
+}  // namespace
+
+int unetk_internal_conv3x3_k32(const void* params, int dtype, void* stream) {
+  const ConvParams& P = *static_cast<const ConvParams*>(params);
+  if (dtype == UNETK_BF16) return dispatch_k32<bf16>(P, (hipStream_t)stream);
+  if (dtype == UNETK_F16) return dispatch_k32<f16>(P, (hipStream_t)stream);
+  return UNETK_ERR_DTYPE;
 }

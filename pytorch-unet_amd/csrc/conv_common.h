@@ -42,12 +42,12 @@ struct ConvParams {
 };
 
 // One k-step: a 16-byte A piece and a 16-byte B piece per lane.
-//   bf16: one v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8h..8h+7)
+//   bf16 / fp16: one v_mfma_f32_32x32x16_{bf16,f16} (lane half h holds k = 8h..8h+7)
 //   fp32: four v_mfma_f32_32x32x2_f32 (lane half h holds k = 4h+e for e = 0..3) -- exact fp32, fmaf-chain numerics
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
+template <typename T> struct Mma {     // the 16-bit element types
   static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    typedef typename H16<T>::x8 h8;
+    c = H16<T>::mfma32(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c);
   }
 };
 template <> struct Mma<float> {
@@ -63,11 +63,11 @@ template <> struct Mma<float> {
 template <typename T, int NB> __device__ __forceinline__ void store_channels(T* p, const float (&v)[NB]) {
   if constexpr (sizeof(T) == 2) {
     if constexpr (NB == 2) {
-      bf16x2 o = {(bf16)v[0], (bf16)v[1]};
+      typename H16<T>::x2 o = {(T)v[0], (T)v[1]};
       __builtin_nontemporal_store(__builtin_bit_cast(unsigned, o), reinterpret_cast<unsigned*>(p));
     } else {
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      typename H16<T>::x4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
       __builtin_nontemporal_store(__builtin_bit_cast(u32x2, o), reinterpret_cast<u32x2*>(p));
     }
   } else {
@@ -83,7 +83,7 @@ template <typename T, int NB> __device__ __forceinline__ void store_channels(T* 
 
 }  // namespace
 
-// conv3x3_k32.hip: the bf16 conv3x3 kernel on v_mfma_f32_16x16x32_bf16 (K = 32 input channels of one tap per
+// conv3x3_k32.hip: the 16-bit conv3x3 kernel on v_mfma_f32_16x16x32_{bf16,f16} (K = 32 input channels of one tap per
 // instruction); reads the "k32" packed weight format (conv_config.h).  Same parameter block as the kernels of
-// conv_igemm.hip, which dispatches to it.
-int unetk_internal_conv3x3_k32(const void* params, void* stream);
+// conv_igemm.hip, which dispatches to it.  dtype: UNETK_BF16 or UNETK_F16.
+int unetk_internal_conv3x3_k32(const void* params, int dtype, void* stream);

@@ -168,9 +168,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
     bool done = false;
     if constexpr (sizeof(T) == 2) {
       // interior tiles, training path: as in conv3x3_db_kernel -- round once into packed pixel pairs, statistics by
-      // v_dot2c_f32_bf16, the two-channel store words gathered with v_perm, no per-element predicates
+      // v_dot2c_f32_bf16 / v_dot2_f32_f16, the two-channel store words gathered with v_perm, no per-element predicates
       if (!aff && (y0 + 8 <= P.H) && (x0 + 32 <= P.W)) {
-        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+        typedef typename H16<T>::x2 h2;
+        const h2 one2 = {(T)1.0f, (T)1.0f};
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           const int yy = y0 + 2 * wid + mb;
@@ -181,10 +182,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
             unsigned pk[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-              const bf16x2 y2 = {(bf16)acc[mb][nb][i], (bf16)acc[mb][nb][i + 1]};
+              const h2 y2 = {(T)acc[mb][nb][i], (T)acc[mb][nb][i + 1]};
               pk[nb] = __builtin_bit_cast(unsigned, y2);
-              ssum[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, ssum[nb], false);
-              ssq[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, ssq[nb], false);
+              ssum[nb] = H16<T>::dot2(y2, one2, ssum[nb]);
+              ssq[nb] = H16<T>::dot2(y2, y2, ssq[nb]);
             }
             __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x05040100u),
                                         reinterpret_cast<unsigned*>(rowp + ri * P.ldy));
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
   }
 }
 
-// ------------------------------------------------------------------------------------------ wgrad, bf16
+// ------------------------------------------------------------------------------------------ wgrad, 16-bit elements
 __device__ uint4 g_zero_page_first[8];
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -258,7 +259,10 @@ struct FirstWgradParams {
 
 // rows i = k = tap*4 + ci (36 used of 64), cols = 64 output channels, GEMM-K = pixels.
 // Each wave takes 2 of the 8 tile rows and keeps a full 64x64 accumulator; waves are summed through LDS at the end.
+template <typename H>
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgradParams P) {
+  typedef typename H16<H>::x8 h8;
+  typedef typename H16<H>::x4 h4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_dy = smem;                 // [256 px][64 co] bf16, 128-B rows, 16-B pieces XOR-swizzled
   char* lds_x = smem + 256 * 128;      // [340][4] bf16
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
     const int y0 = ty * 8, x0 = tx * 32;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // dy tile by LDS-DMA
-    const bf16* dimg = reinterpret_cast<const bf16*>(P.dy) + (size_t)img * P.H * P.W * P.lddy + ct * 64;
+    const H* dimg = reinterpret_cast<const H*>(P.dy) + (size_t)img * P.H * P.W * P.lddy + ct * 64;
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
       const int fi = f * 4 + wid;
@@ -335,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
         const float* src = ximg + (size_t)(yy * P.W + xx) * P.ldx;
         for (int c = 0; c < P.Cin; ++c) v[c] = src[c];
       }
-      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *reinterpret_cast<bf16x4*>(lds_x + p * 8) = o;
+      h4 o = {(H)v[0], (H)v[1], (H)v[2], (H)v[3]};
+      *reinterpret_cast<h4*>(lds_x + p * 8) = o;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -345,28 +349,28 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
       const int row = 2 * wid + rr;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 bfr[2], afr[2];
+        h8 bfr[2], afr[2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
           const char* base = lds_dy + row * 4096;
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(base + addrB[jb][ks][0]));
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(base + addrB[jb][ks][1]));
-          bfr[jb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          bfr[jb] = __builtin_bit_cast(h8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
           const char* base = lds_x + (row * 34 + ks * 16) * 8 + addrA[ib];
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
-            const bf16 v = *reinterpret_cast<const bf16*>(base + jj * 8);
-            afr[ib][jj] = rowok[ib] ? v : (bf16)0.f;
+            const H v = *reinterpret_cast<const H*>(base + jj * 8);
+            afr[ib][jj] = rowok[ib] ? v : (H)0.f;
           }
         }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb)
-            acc[ib][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ib], bfr[jb], acc[ib][jb], 0, 0, 0);
+            acc[ib][jb] = H16<H>::mfma32(afr[ib], bfr[jb], acc[ib][jb]);
       }
     }
   }
@@ -575,9 +579,9 @@ extern "C" {
 static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, const float* scale,
                        const float* shift, int n, int h, int wd, int c_in, int c_out, int dtype, void* stream) {
   if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || ldx < c_in || ldy < c_out) return UNETK_ERR_SHAPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if ((reinterpret_cast<uintptr_t>(y) & 15) || (ldy * es) % 16) return UNETK_ERR_ALIGN;
   if ((long)h * wd * ldy >= 0x7fffffffL) return UNETK_ERR_SHAPE;
   FirstParams P{};
@@ -590,10 +594,7 @@ static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy
   const long groups = spatial < 2048 ? spatial : 2048;
   const long nblk = groups * P.n_tiles;
   const size_t lds = 340 * 16 + 5 * 2 * 1024;
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(conv_first_fprop_kernel<bf16>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
-  else
-    hipLaunchKernelGGL(conv_first_fprop_kernel<float>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv_first_fprop_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -619,22 +620,22 @@ int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out
 int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                               int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
                               void* stream) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   const int64_t need = unetk_conv3x3_first_wgrad_workspace_bytes(n, h, w, c_out);
   if (need < 0) return (int)need;
   if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
   if (c_in < 1 || c_in > 4 || ldx < c_in || lddy < c_out) return UNETK_ERR_SHAPE;
-  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (lddy * (dtype == UNETK_BF16 ? 2 : 4)) % 16) return UNETK_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(dy) & 15) || (lddy * unetk_esize(dtype)) % 16) return UNETK_ERR_ALIGN;
   FirstWgradParams P{};
   P.x = x; P.dy = dy; P.slab = (float*)workspace;
   P.N = n; P.H = h; P.W = w; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.lddy = lddy;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.col_tiles = c_out / 64;
   P.nsplit = first_nsplit(P.ntiles, P.col_tiles);
-  if (dtype == UNETK_BF16) {
+  if (unetk_is16(dtype)) {
     const size_t lds = 256 * 128 + 340 * 8;
-    hipLaunchKernelGGL(conv_first_wgrad_bf16_kernel, dim3(P.nsplit * P.col_tiles), dim3(256), lds, (hipStream_t)stream,
-                       P);
+    UNETK_WITH_H(dtype, hipLaunchKernelGGL(conv_first_wgrad_bf16_kernel<H>, dim3(P.nsplit * P.col_tiles), dim3(256), lds,
+                                           (hipStream_t)stream, P));
   } else {
     FirstWgradParams Q = P;
     Q.col_tiles = c_out / 32;     // the fp32 kernel works on 32-channel column tiles, same slab layout
@@ -652,20 +653,16 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
 int unetk_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int lddx, int n, int h, int wd,
                               int c_in, int c_out, int dtype, void* stream) {
   if (!dy || !w || !dx || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || c_out > 512 || lddx < c_in || lddy < c_out) return UNETK_ERR_SHAPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if ((reinterpret_cast<uintptr_t>(dy) & 15) || (lddy * es) % 16) return UNETK_ERR_ALIGN;
   const long npix = (long)n * h * wd;
   long g = (npix + 255) / 256;
   if (g > 4096) g = 4096;
   const size_t lds = (size_t)9 * c_out * 16;
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(conv_first_dgrad_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16*)dy, lddy, w, dx, lddx, n, h, wd, c_in, c_out);
-  else
-    hipLaunchKernelGGL(conv_first_dgrad_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                       (const float*)dy, lddy, w, dx, lddx, n, h, wd, c_in, c_out);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv_first_dgrad_kernel<T>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const T*)dy, lddy, w, dx, lddx, n, h, wd, c_in, c_out));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

@@ -659,7 +659,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
       if ((y0 + TR <= P.H) && (x0 + 32 <= P.W) && !(P.dbg & 4)) {
         auto fast = [&](auto stats_c) {
           constexpr bool ST = decltype(stats_c)::value;
-          const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+          typedef typename H16<T>::x2 h2;
+          const h2 one2 = {(T)1.0f, (T)1.0f};
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) {
             const int yy = y0 + MB * wid + mb;
@@ -670,11 +671,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(ConvParams P) {
               unsigned pk[NB];
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) {
-                const bf16x2 y2 = {(bf16)acc[mb][nb][i], (bf16)acc[mb][nb][i + 1]};
+                const h2 y2 = {(T)acc[mb][nb][i], (T)acc[mb][nb][i + 1]};
                 pk[nb] = __builtin_bit_cast(unsigned, y2);
                 if constexpr (ST) {
-                  ssum[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, one2, ssum[nb], false);
-                  ssq[nb] = __builtin_amdgcn_fdot2_f32_bf16(y2, y2, ssq[nb], false);
+                  ssum[nb] = H16<T>::dot2(y2, one2, ssum[nb]);
+                  ssq[nb] = H16<T>::dot2(y2, y2, ssq[nb]);
                 }
                 acc[mb][nb][i] = 0.f;
                 acc[mb][nb][i + 1] = 0.f;
@@ -981,10 +982,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
               unsigned d[2][2];
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
-                bf16x2 lo = {(bf16)(acc[mb][0][i + e] + bias[0]), (bf16)(acc[mb][1][i + e] + bias[1])};
-                bf16x2 hi = {(bf16)(acc[mb][2][i + e] + bias[2]), (bf16)(acc[mb][3][i + e] + bias[3])};
-                d[e][0] = __builtin_bit_cast(unsigned, lo);
-                d[e][1] = __builtin_bit_cast(unsigned, hi);
+                d[e][0] = pack2<T>(acc[mb][0][i + e] + bias[0], acc[mb][1][i + e] + bias[1]);
+                d[e][1] = pack2<T>(acc[mb][2][i + e] + bias[2], acc[mb][3][i + e] + bias[3]);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i + e] = 0.f;
               }
@@ -1128,9 +1127,9 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     // conv3x3 always runs the double-buffered LDS-DMA kernel (conv3x3_db_kernel); the register-staged first generation
     // below still serves the transposed-conv modes whose GEMM-N is not a multiple of 128
     const Conv3Config cfg = conv3_config(P.Cout);
-    if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+    if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
     // bf16: the 16x16x32 kernel (conv3x3_k32.hip) and its weight format; the packer asks the same function
-    if (conv3_use_k32(dtype == UNETK_BF16, P.Cout)) return unetk_internal_conv3x3_k32(&P, s);
+    if (conv3_use_k32(unetk_is16(dtype), P.Cout)) return unetk_internal_conv3x3_k32(&P, dtype, s);
 #ifdef UNETK_TUNING
     // A/B builds only (UNETK_CONV_K32=0/1): the 32x32x16 bf16 instantiations of conv3x3_db_kernel, superseded by the
     // 16x16x32 kernels above and not compiled into the shipped library
@@ -1143,7 +1142,7 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       return cfg.NB == 4 ? launch_db<bf16, 4, 1, 8, 2, 2>(P, s) : launch_db<bf16, 2, 2, 8>(P, s);
     }
 #endif
-    // from here on: fp32 (exact-fp32 MFMA); the inference epilogue exists in bf16 only (BASELINE.json configs[2])
+    // from here on: fp32 (exact-fp32 MFMA); the inference epilogue exists for 16-bit elements only (BASELINE.json configs[2])
     if (dtype != UNETK_F32 || P.aff_scale != nullptr) return UNETK_ERR_DTYPE;
     // 128-channel tiles: 64-byte input rows (KI = 2) refilled every second weight chunk; 64-channel tiles: 16 x 32
     // pixels, 32-channel chunks (measured slower and removed: 32-byte rows for the wide tiles -7 %, 32 x 32-pixel
@@ -1160,14 +1159,16 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       // GEMM-K up to 1024: 4-wave workgroups, two per CU (measured at the four decoder levels: forward 0.48 -> 0.41,
       // 0.35 -> 0.31, 0.23 -> 0.20, 0.22 -> 0.21 ms; dgrad 0.42 -> 0.40, 0.30 -> 0.29 ms; K = 2048 dgrad 0.21 -> 0.22)
       UNETK_KNOB(small, "UNETK_PW_SMALL", 1024);
-      if (dtype == UNETK_BF16 && P.Cin * (MODE == 2 ? 4 : 1) <= small) return launch_pw<bf16, MODE, 4, 2>(P, s);
-      if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
+      const bool few_k = P.Cin * (MODE == 2 ? 4 : 1) <= small;
+      if (dtype == UNETK_BF16) return few_k ? launch_pw<bf16, MODE, 4, 2>(P, s) : launch_pw<bf16, MODE>(P, s);
+      if (dtype == UNETK_F16) return few_k ? launch_pw<f16, MODE, 4, 2>(P, s) : launch_pw<f16, MODE>(P, s);
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
       return UNETK_ERR_DTYPE;
     }
   }
   if constexpr (MODE != 0) {       // the first-generation kernel serves only the transposed-conv modes
     if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);
+    if (dtype == UNETK_F16) return launch<f16, 2, MODE>(P, s);
     if (dtype == UNETK_F32) return launch<float, 2, MODE>(P, s);
   }
   return UNETK_ERR_DTYPE;
@@ -1177,8 +1178,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 int check_common(const void* x, int ldx, int xoff, const void* y, int ldy, int yoff, int cin, int cout, int dtype,
                  int chunk_bytes) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int es = unetk_esize(dtype);
   const int ch = chunk_bytes / es;
   if (cin <= 0 || cout <= 0 || cin % ch != 0 || cout % 64 != 0) return UNETK_ERR_SHAPE;
   if (ldx < xoff + cin || ldy < yoff + cout || xoff < 0 || yoff < 0) return UNETK_ERR_SHAPE;
@@ -1204,7 +1205,7 @@ int conv3x3_common(const void* x, int ldx, int xoff, const void* wpk, void* y, i
   P.x = x; P.wpk = wpk; P.y = y; P.stats = stats; P.aff_scale = aff_scale; P.aff_shift = aff_shift;
   P.pool = pool; P.ldp = ldp;
   if (bnr != nullptr) {
-    const int es = dtype == UNETK_BF16 ? 2 : 4;
+    const int es = unetk_esize(dtype);
     if (!bnr->z || !bnr->scale || !bnr->shift || !bnr->mean || !bnr->invstd || !stats) return UNETK_ERR_ARG;
     if (bnr->ldz < cout || (long)h * w * bnr->ldz >= 0x7fffffffL) return UNETK_ERR_SHAPE;
     if (!aligned16(bnr->z) || (bnr->ldz * es) % 16) return UNETK_ERR_ALIGN;
@@ -1231,7 +1232,7 @@ int unetk_conv3x3_fprop_bn_relu(const void* x, int ldx, int x_choff, const void*
                                 int w, int c_in, int c_out, int dtype, void* stream) {
   if (!scale || !shift) return UNETK_ERR_ARG;
   if (pool) {
-    const int es = dtype == UNETK_BF16 ? 2 : 4;
+    const int es = unetk_esize(dtype);
     if (h < 2 || w < 2 || ldp < c_out) return UNETK_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(pool) & 15) || (ldp * es) % 16) return UNETK_ERR_ALIGN;
   }
@@ -1252,7 +1253,7 @@ int unetk_conv3x3_dgrad_sums(const void* dy, int lddy, int dy_choff, const void*
 
 int unetk_conv3x3_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype) {
   // mirrors dispatch<0> / unetk_internal_conv3x3_k32: GEMM-N = c_in, GEMM-K = c_out
-  if (dtype != UNETK_BF16 || c_in <= 0 || c_out < 64 || c_out % 32 != 0) return 0;
+  if (!unetk_is16(dtype) || c_in <= 0 || c_out < 64 || c_out % 32 != 0) return 0;
   return conv3_use_k32(1, c_in) && conv3_k32_nb16(c_in) == 4 && c_in == 64 && !conv3_k32_nopipe();
 }
 
@@ -1267,7 +1268,7 @@ int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const 
   // the kernel serving this shape has no such epilogue: plain dgrad, then the stand-alone reduction pass
   if (int e2 = conv3x3_common(dy, lddy, dy_choff, wpk, dx, lddx, dx_choff, nullptr, n, h, w, c_out, c_in, dtype, stream))
     return e2;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   return unetk_bn_relu_bwd_reduce(static_cast<const char*>(dx) + (size_t)dx_choff * es, lddx, z_prev, ldz, scale, shift,
                                   mean, invstd, sums, (int64_t)n * h * w, c_in, dtype, stream);
 }

@@ -16,7 +16,7 @@ template <typename T> struct Vec {
     const uint4 raw = *reinterpret_cast<const uint4*>(p);
 #endif
     if constexpr (sizeof(T) == 2) {
-      const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+      const typename H16<T>::x8 b = __builtin_bit_cast(typename H16<T>::x8, raw);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
     } else {
@@ -27,9 +27,9 @@ template <typename T> struct Vec {
   }
   static __device__ __forceinline__ void store(T* p, const float (&v)[E]) {
     if constexpr (sizeof(T) == 2) {
-      bf16x8 b;
+      typename H16<T>::x8 b;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
+      for (int i = 0; i < 8; ++i) b[i] = (T)v[i];
       put(p, __builtin_bit_cast(uint4, b));
     } else {
       f32x4 f = {v[0], v[1], v[2], v[3]};
@@ -375,10 +375,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_fixed_kernel(
 // The quad's operands stay packed (16-byte registers) until the element they belong to is processed.  Measured
 // (scripts/perf_bn_pool.py): letting hipcc take ~195 VGPRs (2 waves/SIMD, no scratch) runs at 4.8-5.5 TB/s; capping
 // it at 128 or 170 VGPRs by launch bounds spills and drops to 3.4-4.3 TB/s.
-template <typename T> __device__ __forceinline__ float raw_elem(const uint4& r, int i);
-template <> __device__ __forceinline__ float raw_elem<bf16>(const uint4& r, int i) {
+template <typename T> __device__ __forceinline__ float raw_elem(const uint4& r, int i) {
   const unsigned w = (i >> 1) == 0 ? r.x : (i >> 1) == 1 ? r.y : (i >> 1) == 2 ? r.z : r.w;
-  return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  return (i & 1) ? H16<T>::hi(w) : H16<T>::lo(w);
 }
 template <> __device__ __forceinline__ float raw_elem<float>(const uint4& r, int i) {
   return __uint_as_float(i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w);
@@ -1117,8 +1116,8 @@ __global__ void double_to_float_kernel(const double* in, float* out, int n) {
 bool ok16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int check_act(const void* p, int ld, int c, int dtype) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4, e = 16 / es;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int es = unetk_esize(dtype), e = 16 / es;
   if (!p) return UNETK_ERR_ARG;
   if (c <= 0 || c % e || ld < c) return UNETK_ERR_SHAPE;
   if (!ok16(p) || (ld * es) % 16) return UNETK_ERR_ALIGN;
@@ -1127,8 +1126,7 @@ int check_act(const void* p, int ld, int c, int dtype) {
 
 }  // namespace
 
-#define DISPATCH_T(dtype, ...)                   \
-  if ((dtype) == UNETK_BF16) { using T = bf16; __VA_ARGS__; } else { using T = float; __VA_ARGS__; }
+#define DISPATCH_T(dtype, ...) UNETK_WITH_T(dtype, __VA_ARGS__)
 
 extern "C" {
 
@@ -1177,7 +1175,7 @@ int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy,
   if (int e = check_act(dout, lddo, c, dtype)) return e;
   if (int e = check_act(y, ldy, c, dtype)) return e;
   if (!scale || !shift || !mean || !invstd || !sums || npix <= 0) return UNETK_ERR_ARG;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   const int ppp = c / e_;
   const int pg = ppp < 256 ? ppp : 256;
   if (256 % pg) return UNETK_ERR_SHAPE;   // channel counts are multiples of 64: pg is a power of two
@@ -1228,7 +1226,7 @@ int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const f
   if (!y || !scale || !shift || !out || !w || !bias || !logits || npix <= 0) return UNETK_ERR_ARG;
   if (int e = check_act(y, ldy, c, dtype)) return e;
   if (int e = check_act(out, ldo, c, dtype)) return e;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int E = unetk_epp(dtype);
   const int ppp = c / E;
   // a pixel's lanes must share a wave for the shuffle sum: ppp a power of two <= 64
   if (n_classes < 1 || n_classes > kHeadMax || ldl < n_classes || ppp > 64 || (ppp & (ppp - 1))) return UNETK_ERR_SHAPE;
@@ -1251,11 +1249,11 @@ int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const f
 static int head_bwd_check(const void* dl, int lddl, const float* w, int ncls, const void* y, int ldy, int64_t npix,
                           int c, int dtype) {
   if (!dl || !w || !y || npix <= 0 || c <= 0) return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int E = unetk_epp(dtype);
   if (ncls < 1 || ncls > kHeadMax || lddl < ncls) return UNETK_ERR_SHAPE;   // more classes: conv1x1_dgrad + plain passes
   if (c % E || c / E > 256 || 256 % (c / E) || ldy < c) return UNETK_ERR_SHAPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if ((ldy * es) % 16 || (reinterpret_cast<uintptr_t>(y) & 15)) return UNETK_ERR_ALIGN;
   return UNETK_OK;
 }
@@ -1265,7 +1263,7 @@ int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int 
                                   double* sums, double* head_sums, int64_t npix, int c, int dtype, void* stream) {
   if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
   if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int E = unetk_epp(dtype);
   const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 1024);
 #define HEAD_REDUCE(NC)                                                                                              \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_head_kernel<T, NC>), dim3(grid), dim3(256), 0,            \
@@ -1297,7 +1295,7 @@ int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n
   if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
   if (!scale || !shift || !mean || !coef) return UNETK_ERR_ARG;
   if (int e = check_act(dy, lddy, c, dtype)) return e;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int E = unetk_epp(dtype);
   const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 256 * EW_BWD_MUL);
 #define HEAD_APPLY(NC)                                                                                               \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_head_kernel<T, NC>), dim3(grid), dim3(256), 0,             \
@@ -1317,11 +1315,11 @@ int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n
 static int pool_bwd_check(const void* dskip, int ldds, const void* dpool, int lddp, const void* y, int ldy, int n,
                           int h, int w, int c, int dtype) {
   if (!dskip || !dpool || !y || n <= 0 || h < 2 || w < 2 || c <= 0) return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int E = unetk_epp(dtype);
   if (c % E || c / E > 256 || 256 % (c / E)) return UNETK_ERR_SHAPE;   // callers fall back to max-pool backward + plain BN backward
   if (ldds < c || lddp < c || ldy < c) return UNETK_ERR_SHAPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if ((ldds * es) % 16 || (lddp * es) % 16 || (ldy * es) % 16) return UNETK_ERR_ALIGN;
   if ((reinterpret_cast<uintptr_t>(dskip) | reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(y)) & 15)
     return UNETK_ERR_ALIGN;
@@ -1333,7 +1331,7 @@ int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool
                                   double* sums, int n, int h, int w, int c, int dtype, void* stream) {
   if (int e = pool_bwd_check(dskip, ldds, dpool, lddp, y, ldy, n, h, w, c, dtype)) return e;
   if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int E = unetk_epp(dtype);
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
   const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -1348,7 +1346,7 @@ int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool,
                                  int lddy, int n, int h, int w, int c, int dtype, void* stream) {
   if (int e = pool_bwd_check(dskip, ldds, dpool, lddp, y, ldy, n, h, w, c, dtype)) return e;
   if (!scale || !shift || !mean || !coef || !dy || lddy < c) return UNETK_ERR_ARG;
-  const int E = dtype == UNETK_BF16 ? 8 : 4;
+  const int E = unetk_epp(dtype);
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
   const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -1377,7 +1375,7 @@ int unetk_maxpool2x2_bwd(const void* x, int ldx, const void* dpool, int lddp, co
   if (dskip)
     if (int e = check_act(dskip, ldds, c, dtype)) return e;
   if (n <= 0 || h < 2 || w < 2) return UNETK_ERR_SHAPE;
-  const long items = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  const long items = (long)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / unetk_epp(dtype));
   DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)x, ldx, (const T*)dpool, lddp, (const T*)dskip, ldds, (T*)dx, lddx, n,
                                        h, w, c));
@@ -1391,7 +1389,7 @@ int unetk_bilinear2x_fwd(const void* x, int ldx, void* out, int ldo, int n, int 
   if (int e = check_act(out, ldo, c, dtype)) return e;
   if (n <= 0 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws)
     return UNETK_ERR_SHAPE;
-  const int per_row = ws * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  const int per_row = ws * (c / unetk_epp(dtype));
   if ((long)n * hs > 0x7fffffffL || (long)h * w >= 0x7fffffffL) return UNETK_ERR_SHAPE;
   const int gx = (per_row + 255) / 256 > 8 ? 8 : (per_row + 255) / 256;
   const long rows = (long)n * hs;
@@ -1408,7 +1406,7 @@ int unetk_bilinear2x_bwd(const void* dcat, int ldd, void* dx, int lddx, int n, i
   if (int e = check_act(dx, lddx, c, dtype)) return e;
   if (n <= 0 || h <= 0 || w <= 0 || pad_t < 0 || pad_l < 0 || pad_t + 2 * h > hs || pad_l + 2 * w > ws)
     return UNETK_ERR_SHAPE;
-  const long items = (long)n * h * w * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  const long items = (long)n * h * w * (c / unetk_epp(dtype));
   DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dcat, ldd, (T*)dx, lddx, n, h, w, c, hs, ws, pad_t, pad_l));
   UNETK_CHECK_LAUNCH();
@@ -1432,7 +1430,7 @@ int unetk_zero_pad_border(void* buf, int ld, int n, int hs, int ws, int c, int p
   if (n <= 0 || pad_t < 0 || pad_l < 0 || pad_t + h_up > hs || pad_l + w_up > ws) return UNETK_ERR_SHAPE;
   if (h_up == hs && w_up == ws) return UNETK_OK;   // nothing to pad
   if ((long)hs * ws >= 0x7fffffffL) return UNETK_ERR_SHAPE;
-  const long items = (long)n * ((long)hs * ws - (long)h_up * w_up) * (c / (dtype == UNETK_BF16 ? 8 : 4));
+  const long items = (long)n * ((long)hs * ws - (long)h_up * w_up) * (c / unetk_epp(dtype));
   DISPATCH_T(dtype, hipLaunchKernelGGL(zero_border_kernel<T>, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream,
                                        (T*)buf, ld, n, hs, ws, c, pad_t, pad_l, h_up, w_up));
   UNETK_CHECK_LAUNCH();
@@ -1447,7 +1445,7 @@ int unetk_channel_sum(const void* x, int ld, int n, int hs, int ws, int c, int w
     return UNETK_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(scratch, 0, (size_t)c * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   const int ppp = c / e_;
   const int pg = ppp < 256 ? ppp : 256;
   if (256 % pg) return UNETK_ERR_SHAPE;
@@ -1471,7 +1469,7 @@ int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_of
     return UNETK_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(scratch, 0, (size_t)c_up * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   const int ppp = c_up / e_;
   const int pg = ppp < 256 ? ppp : 256;
   if (256 % pg) return UNETK_ERR_SHAPE;
@@ -1499,7 +1497,7 @@ int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_of
 
 int unetk_predict_mask(const void* logits, int ld, int n, int h, int w, int n_classes, int out_h, int out_w,
                        float threshold, int64_t* mask, int dtype, void* stream) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   if (!logits || !mask) return UNETK_ERR_ARG;
   if (n <= 0 || h <= 0 || w <= 0 || n_classes <= 0 || ld < n_classes || out_h <= 0 || out_w <= 0) return UNETK_ERR_SHAPE;
   const long total = (long)n * out_h * out_w;
@@ -1516,7 +1514,7 @@ int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const f
   if (int e = check_act(pool, ldp, c, dtype)) return e;
   if (!scale || !shift) return UNETK_ERR_ARG;
   if (n <= 0 || h < 2 || w < 2) return UNETK_ERR_SHAPE;
-  const int ppp = c / (dtype == UNETK_BF16 ? 8 : 4);
+  const int ppp = c / unetk_epp(dtype);
   if (ppp > 256 || 256 % ppp) return UNETK_ERR_SHAPE;   // callers fall back to apply + maxpool2x2_fwd
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_pool_kernel<T>, dim3(ew_grid(nquads, 256 / ppp, 256 * 4)), dim3(256),

@@ -11,7 +11,7 @@ namespace {
 template <typename T> __device__ __forceinline__ void load_piece(const T* p, float* v) {
   const uint4 raw = *reinterpret_cast<const uint4*>(p);
   if constexpr (sizeof(T) == 2) {
-    const bf16x8 b = __builtin_bit_cast(bf16x8, raw);
+    const typename H16<T>::x8 b = __builtin_bit_cast(typename H16<T>::x8, raw);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)b[i];
   } else {
@@ -23,9 +23,9 @@ template <typename T> __device__ __forceinline__ void load_piece(const T* p, flo
 
 template <typename T> __device__ __forceinline__ void store_piece(T* p, const float* v) {
   if constexpr (sizeof(T) == 2) {
-    bf16x8 b;
+    typename H16<T>::x8 b;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = (bf16)v[i];
+    for (int i = 0; i < 8; ++i) b[i] = (T)v[i];
     __builtin_nontemporal_store(__builtin_bit_cast(f32x4, b), reinterpret_cast<f32x4*>(p));
   } else {
     f32x4 f = {v[0], v[1], v[2], v[3]};
@@ -360,8 +360,8 @@ size_t head_tiled_lds(int ncls, int es_out) {
 constexpr int kWgradBlocks = 2048;
 
 int check_head(const void* x, int ldx, int cin, int ncls, int dtype) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4, e = 16 / es;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int es = unetk_esize(dtype), e = 16 / es;
   if (!x) return UNETK_ERR_ARG;
   if (cin <= 0 || ncls <= 0 || cin % e || ldx < cin || (long)ncls * cin > 12288) return UNETK_ERR_SHAPE;
   const int ppp = cin / e;
@@ -378,18 +378,14 @@ int unetk_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias,
                       int c_in, int n_classes, int dtype, void* stream) {
   if (int e = check_head(x, ldx, c_in, n_classes, dtype)) return e;
   if (!w || !bias || !out || npix <= 0 || ldo < n_classes) return UNETK_ERR_ARG;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   if (n_classes > CT && n_classes <= 4 * kHeadMaxGroup && c_in == kHeadCin && ldo == n_classes &&
       (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-    const size_t lds = head_tiled_lds(n_classes, dtype == UNETK_BF16 ? 2 : 4);
+    const size_t lds = head_tiled_lds(n_classes, unetk_esize(dtype));
     long gx = (npix + kHeadPix - 1) / kHeadPix;
     if (gx > 1024) gx = 1024;
-    if (dtype == UNETK_BF16)
-      hipLaunchKernelGGL(conv1x1_fwd_tiled_kernel<bf16>, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream,
-                         (const bf16*)x, ldx, w, bias, (bf16*)out, (long)npix, n_classes);
-    else
-      hipLaunchKernelGGL(conv1x1_fwd_tiled_kernel<float>, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream,
-                         (const float*)x, ldx, w, bias, (float*)out, (long)npix, n_classes);
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv1x1_fwd_tiled_kernel<T>, dim3((unsigned)gx), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)x, ldx, w, bias, (T*)out, (long)npix, n_classes));
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
@@ -401,12 +397,8 @@ int unetk_conv1x1_fwd(const void* x, int ldx, const float* w, const float* bias,
   if (gx > 2048) gx = 2048;
   dim3 grid((unsigned)gx, (unsigned)((n_classes + CT - 1) / CT));
   const size_t lds = (size_t)CT * c_in * sizeof(float);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(conv1x1_fwd_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)x, ldx, w, bias,
-                       (bf16*)out, ldo, (long)npix, c_in, n_classes, G);
-  else
-    hipLaunchKernelGGL(conv1x1_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, ldx, w,
-                       bias, (float*)out, ldo, (long)npix, c_in, n_classes, G);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv1x1_fwd_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, ldx, w, bias,
+                       (T*)out, ldo, (long)npix, c_in, n_classes, G));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -415,16 +407,12 @@ int unetk_conv1x1_dgrad(const void* dl, int lddl, const float* w, void* dx, int 
                         int n_classes, int dtype, void* stream) {
   if (int e = check_head(dx, lddx, c_in, n_classes, dtype)) return e;
   if (!w || !dl || npix <= 0 || lddl < n_classes) return UNETK_ERR_ARG;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   long g = (npix * (c_in / e_) + 255) / 256;
   if (g > 2048) g = 2048;
   const size_t lds = (size_t)n_classes * c_in * sizeof(float);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(conv1x1_dgrad_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16*)dl, lddl, w, (bf16*)dx, lddx, (long)npix, c_in, n_classes);
-  else
-    hipLaunchKernelGGL(conv1x1_dgrad_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                       (const float*)dl, lddl, w, (float*)dx, lddx, (long)npix, c_in, n_classes);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv1x1_dgrad_kernel<T>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                       (const T*)dl, lddl, w, (T*)dx, lddx, (long)npix, c_in, n_classes));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -439,17 +427,13 @@ int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float*
   if (int e = check_head(x, ldx, c_in, n_classes, dtype)) return e;
   if (!dl || !dw || !workspace || npix <= 0 || lddl < n_classes) return UNETK_ERR_ARG;
   if (workspace_bytes < unetk_conv1x1_wgrad_workspace_bytes(c_in, n_classes)) return UNETK_ERR_ARG;
-  const int e_ = dtype == UNETK_BF16 ? 8 : 4;
+  const int e_ = unetk_epp(dtype);
   if (n_classes > CT && n_classes <= 4 * kHeadMaxGroup && c_in == kHeadCin && lddl == n_classes) {
     long gt = (npix + kHeadPix - 1) / kHeadPix;
     if (gt > 1024) gt = 1024;
     const size_t lds = head_tiled_lds(n_classes, 4) - (size_t)n_classes * kHeadCin * sizeof(float);
-    if (dtype == UNETK_BF16)
-      hipLaunchKernelGGL(conv1x1_wgrad_tiled_kernel<bf16>, dim3((unsigned)gt), dim3(256), lds, (hipStream_t)stream,
-                         (const bf16*)x, ldx, (const bf16*)dl, (float*)workspace, (long)npix, n_classes);
-    else
-      hipLaunchKernelGGL(conv1x1_wgrad_tiled_kernel<float>, dim3((unsigned)gt), dim3(256), lds, (hipStream_t)stream,
-                         (const float*)x, ldx, (const float*)dl, (float*)workspace, (long)npix, n_classes);
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv1x1_wgrad_tiled_kernel<T>, dim3((unsigned)gt), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)x, ldx, (const T*)dl, (float*)workspace, (long)npix, n_classes));
     UNETK_CHECK_LAUNCH();
     hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(n_classes * (c_in + 1)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, (int)gt, dw, db, c_in, n_classes);
@@ -461,12 +445,8 @@ int unetk_conv1x1_wgrad(const void* x, int ldx, const void* dl, int lddl, float*
   if (gx > kWgradBlocks) gx = kWgradBlocks;
   dim3 grid((unsigned)gx, (unsigned)((n_classes + CT - 1) / CT));
   const size_t lds = (size_t)CT * (c_in + 1) * sizeof(float);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(conv1x1_wgrad_kernel<bf16>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)x, ldx,
-                       (const bf16*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes);
-  else
-    hipLaunchKernelGGL(conv1x1_wgrad_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)x, ldx,
-                       (const float*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv1x1_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, ldx,
+                       (const T*)dl, lddl, (float*)workspace, (long)npix, c_in, n_classes));
   UNETK_CHECK_LAUNCH();
   const int total = n_classes * (c_in + 1);
   hipLaunchKernelGGL(conv1x1_wgrad_reduce_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream,

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd2_kernel(const T* __restrict_
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (long)gridDim.x * blockDim.x) {
     float v[8];
     if constexpr (sizeof(T) == 2) {
-      const bf16x8 r = *reinterpret_cast<const bf16x8*>(z + q * 8);
+      const typename H16<T>::x8 r = *reinterpret_cast<const typename H16<T>::x8*>(z + q * 8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
     } else {
@@ -452,7 +452,7 @@ bool loss_tiled_ok(const void* z, int ldz, const void* dz, int lddz, int ncls, i
 
 int eval_dice_check(const void* logits, int ld, const int64_t* mask, int n, int64_t hw, int n_classes, int first_class,
                     const float* dice_out, int dtype) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   if (!logits || !mask || !dice_out) return UNETK_ERR_ARG;
   if (n <= 0 || n > 65535 || hw <= 0 || n_classes < 2 || n_classes > 1024 || ld < n_classes || first_class < 0 ||
       first_class >= n_classes)
@@ -469,12 +469,8 @@ int eval_dice_launch(const void* logits, int ld, const int64_t* mask, int n, int
   const long cap = n >= 2048 ? 1 : 2048 / n;
   if (gx > cap) gx = cap;
   const size_t lds = (size_t)4 * n_classes * 3 * sizeof(unsigned);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(eval_counts_kernel<bf16>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s, (const bf16*)logits,
-                       ld, (const long long*)mask, (long)hw, n_classes, counts);
-  else
-    hipLaunchKernelGGL(eval_counts_kernel<float>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s,
-                       (const float*)logits, ld, (const long long*)mask, (long)hw, n_classes, counts);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(eval_counts_kernel<T>, dim3((unsigned)gx, (unsigned)n), dim3(256), lds, s, (const T*)logits,
+                       ld, (const long long*)mask, (long)hw, n_classes, counts));
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(eval_dice_finalize_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)counts, n,
                      n_classes, first_class, eps, dice_out);
@@ -525,36 +521,26 @@ extern "C" {
 int unetk_seg_loss_fwd(const void* logits, int ldz, const int64_t* mask, int64_t npix, int n_classes, float eps,
                        double* sums4, float* out4, int dtype, void* stream) {
   if (!logits || !mask || !sums4 || !out4 || npix <= 0 || n_classes <= 0 || ldz < n_classes) return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums4, 0, 4 * sizeof(double), s) != hipSuccess) return UNETK_ERR_LAUNCH;
   long g = (npix + 255) / 256;
   if (g > 2048) g = 2048;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if (n_classes > 2 && loss_tiled_ok(logits, ldz, nullptr, 0, n_classes, es, false)) {
     const size_t lds = ((size_t)kLossTile * n_classes * es + 15) / 16 * 16;
-    if (dtype == UNETK_BF16)
-      hipLaunchKernelGGL(seg_loss_fwd_tiled_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, s, (const bf16*)logits,
-                         (const long long*)mask, (long)npix, n_classes, sums4);
-    else
-      hipLaunchKernelGGL(seg_loss_fwd_tiled_kernel<float>, dim3((unsigned)g), dim3(256), lds, s, (const float*)logits,
-                         (const long long*)mask, (long)npix, n_classes, sums4);
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(seg_loss_fwd_tiled_kernel<T>, dim3((unsigned)g), dim3(256), lds, s, (const T*)logits,
+                         (const long long*)mask, (long)npix, n_classes, sums4));
   } else if (n_classes == 2 && ldz == 2 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
              (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
     long g2 = (npix / 4 + 255) / 256;
     g2 = g2 < 1 ? 1 : (g2 > 512 ? 512 : g2);
-    if (dtype == UNETK_BF16)
-      hipLaunchKernelGGL(seg_loss_fwd2_kernel<bf16>, dim3((unsigned)g2), dim3(256), 0, s, (const bf16*)logits,
-                         (const long long*)mask, (long)npix, sums4);
-    else
-      hipLaunchKernelGGL(seg_loss_fwd2_kernel<float>, dim3((unsigned)g2), dim3(256), 0, s, (const float*)logits,
-                         (const long long*)mask, (long)npix, sums4);
-  } else if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(seg_loss_fwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, s, (const bf16*)logits, ldz,
-                       (const long long*)mask, (long)npix, n_classes, sums4);
-  else
-    hipLaunchKernelGGL(seg_loss_fwd_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (const float*)logits, ldz,
-                       (const long long*)mask, (long)npix, n_classes, sums4);
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(seg_loss_fwd2_kernel<T>, dim3((unsigned)g2), dim3(256), 0, s, (const T*)logits,
+                         (const long long*)mask, (long)npix, sums4));
+  } else {
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(seg_loss_fwd_kernel<T>, dim3((unsigned)g), dim3(256), 0, s, (const T*)logits, ldz,
+                                           (const long long*)mask, (long)npix, n_classes, sums4));
+  }
   UNETK_CHECK_LAUNCH();
   hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(1), 0, s, (const double*)sums4, (long)npix, eps, out4);
   UNETK_CHECK_LAUNCH();
@@ -565,31 +551,21 @@ int unetk_seg_loss_bwd(const void* logits, int ldz, const int64_t* mask, int64_t
                        const float* out4, const float* grad_out, void* dlogits, int lddz, int dtype, void* stream) {
   if (!logits || !mask || !out4 || !dlogits || npix <= 0 || n_classes <= 0 || ldz < n_classes || lddz < n_classes)
     return UNETK_ERR_ARG;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   long g = (npix + 255) / 256;
   if (g > 2048) g = 2048;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   if (n_classes > 2 && loss_tiled_ok(logits, ldz, dlogits, lddz, n_classes, es, true)) {
     const size_t lds = 2 * (((size_t)kLossTile * n_classes * es + 15) / 16 * 16);
-    if (dtype == UNETK_BF16)
-      hipLaunchKernelGGL(seg_loss_bwd_tiled_kernel<bf16>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                         (const bf16*)logits, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
-                         (bf16*)dlogits);
-    else
-      hipLaunchKernelGGL(seg_loss_bwd_tiled_kernel<float>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
-                         (const float*)logits, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
-                         (float*)dlogits);
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(seg_loss_bwd_tiled_kernel<T>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream,
+                         (const T*)logits, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                         (T*)dlogits));
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(seg_loss_bwd_kernel<bf16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
-                       (bf16*)dlogits, lddz);
-  else
-    hipLaunchKernelGGL(seg_loss_bwd_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
-                       (float*)dlogits, lddz);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(seg_loss_bwd_kernel<T>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)logits, ldz, (const long long*)mask, (long)npix, n_classes, out4, grad_out,
+                       (T*)dlogits, lddz));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

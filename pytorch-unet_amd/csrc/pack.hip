@@ -15,10 +15,10 @@ struct PackGeo { int N, K, taps, KS, outer, NB, fmt; };
 bool pack_geo(int kind, int c_out, int c_in, int dtype, PackGeo* g) {
   switch (kind) {
     case 0:
-      if (conv3_use_k32(dtype == UNETK_BF16, c_out)) { *g = {c_out, c_in, 9, 2, 1, conv3_k32_nb16(c_out), 1}; return true; }
+      if (conv3_use_k32(unetk_is16(dtype), c_out)) { *g = {c_out, c_in, 9, 2, 1, conv3_k32_nb16(c_out), 1}; return true; }
       { const Conv3Config c = conv3_config(c_out); *g = {c_out, c_in, 9, c.KS, 1, c.NB, 0}; return true; }
     case 1:
-      if (conv3_use_k32(dtype == UNETK_BF16, c_in)) { *g = {c_in, c_out, 9, 2, 1, conv3_k32_nb16(c_in), 1}; return true; }
+      if (conv3_use_k32(unetk_is16(dtype), c_in)) { *g = {c_in, c_out, 9, 2, 1, conv3_k32_nb16(c_in), 1}; return true; }
       { const Conv3Config c = conv3_config(c_in); *g = {c_in, c_out, 9, c.KS, 1, c.NB, 0}; return true; }
     case 2: *g = {4 * c_out, c_in, 1, 4, 1, pw_nb(4 * c_out), 0}; return true;
     case 3: *g = {c_in, c_out, 1, 4, 4, pw_nb(c_in), 0}; return true;
@@ -291,12 +291,14 @@ __global__ __launch_bounds__(64 * kPackWaves) void pack_plan_kernel(const PlanIt
       local = unit - it.piece_begin;
       if (it.kind == 0) {
         if (it.dtype == UNETK_BF16) stage_kind0<bf16>(it, local, lane, rows);
+        else if (it.dtype == UNETK_F16) stage_kind0<f16>(it, local, lane, rows);
         else stage_kind0<float>(it, local, lane, rows);
       }
     }
     __syncthreads();
     if (valid) {
       if (it.dtype == UNETK_BF16) emit_unit<bf16>(it, local, lane, rows);
+      else if (it.dtype == UNETK_F16) emit_unit<f16>(it, local, lane, rows);
       else emit_unit<float>(it, local, lane, rows);
     }
     __syncthreads();
@@ -349,9 +351,9 @@ const char* unetk_arch(void) { return "gfx950"; }
 
 int64_t unetk_packed_weight_bytes(int kind, int c_out, int c_in, int dtype) {
   PackGeo g;
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   if (!pack_geo(kind, c_out, c_in, dtype, &g)) return UNETK_ERR_ARG;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  const int es = unetk_esize(dtype);
   const int CH = 2 * g.KS * (16 / es);
   if (c_out <= 0 || c_in <= 0 || g.N % 64 || g.K % CH) return UNETK_ERR_SHAPE;
   return (int64_t)g.N * g.K * g.taps * g.outer * es;
@@ -366,12 +368,8 @@ int unetk_pack_weight(int kind, const float* src, void* dst, int c_out, int c_in
   pack_geo(kind, c_out, c_in, dtype, &g);
   const long npieces = bytes / 16;
   const int grid = (int)((npieces + 255) / 256 > 4096 ? 4096 : (npieces + 255) / 256);
-  if (dtype == UNETK_BF16)
-    hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, kind, c_out,
-                       c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, g.fmt, npieces);
-  else
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, kind,
-                       c_out, c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, g.fmt, npieces);
+  UNETK_WITH_T(dtype, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, kind, c_out,
+                       c_in, g.N, g.K, g.taps, g.KS, g.outer, g.NB, g.fmt, npieces));
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }

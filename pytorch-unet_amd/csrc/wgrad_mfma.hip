@@ -19,11 +19,13 @@
 
 namespace {
 
+typedef unsigned short u16;   // a 16-bit element as the data movement sees it (bf16 or fp16)
+
 __device__ uint4 g_zero_page[8];   // zero-initialised: source of padding for LDS-DMA
 
 struct WgradParams {
-  const bf16* a;      // tap-shifted operand
-  const bf16* b;      // fixed operand
+  const u16* a;      // tap-shifted operand
+  const u16* b;      // fixed operand
   float* slab;
   int N, H, W;        // tile-grid domain (conv3: image; convT: low-res grid)
   int Ca, Cb;         // channels of a (rows) and b (cols)
@@ -34,12 +36,12 @@ struct WgradParams {
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) unsigned frag5_t;   // one 16-byte MFMA operand fragment (wgrad5)
+typedef __attribute__((ext_vector_type(4))) unsigned frag5_t;   // one 16-byte MFMA operand fragment (eight 16-bit elements)
 
-__device__ __forceinline__ bf16x8 tr_read8(const char* lds0, const char* lds1) {
+__device__ __forceinline__ frag5_t tr_read8(const char* lds0, const char* lds1) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)lds0);
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)lds1);
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(frag5_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // swizzle of the 16-byte piece index inside a 128-byte pixel row: pixels p and p+2 (same 128-byte half of
@@ -47,9 +49,11 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds0, const char* lds1) {
 __device__ __forceinline__ int swz(int p) { return ((p >> 1) & 1) << 2; }
 
 
-#define WG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// H = the 16-bit element type of the kernel (bf16 or f16): the kernels move 16-bit words (u16) and differ only here
+#define WG_MFMA(a, b, c) \
+  H16<H>::mfma32(__builtin_bit_cast(typename H16<H>::x8, a), __builtin_bit_cast(typename H16<H>::x8, b), c)
 
-template <int MODE>   // 0 conv3x3, 1 convT2x2
+template <typename H, int MODE>   // 0 conv3x3, 1 convT2x2
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
   constexpr int TAPS = MODE == 0 ? 9 : 4;
   constexpr int APITCH = MODE == 0 ? 36 : 32;            // pixels per LDS row of the A tile (multiple of 4)
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
     const int y0 = ty * 8, x0 = tx * 32;
 
     // B tile: 256 pixels x 64 channels of the un-shifted operand
-    const bf16* bimg = P.b + (size_t)img * P.H * P.W * P.ldb + c0;
+    const u16* bimg = P.b + (size_t)img * P.H * P.W * P.ldb + c0;
     auto issue_b = [&]() {
 #pragma unroll
       for (int f = 0; f < B_INSTR / 4; ++f) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
       }
     };
     auto issue_a = [&](int tap) {
-      const bf16* aimg = P.a + (size_t)img * (MODE == 0 ? P.H * P.W : P.Ha * P.Wa) * P.lda + r0;
+      const u16* aimg = P.a + (size_t)img * (MODE == 0 ? P.H * P.W : P.Ha * P.Wa) * P.lda + r0;
 #pragma unroll
       for (int f = 0; f < (A_INSTR + 3) / 4; ++f) {
         const int fi = f * 4 + wid;
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
         const char* brow = lds_b + tr * 4096;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
+          const frag5_t bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-              const bf16x8 af = tr_read8(arow + kh * (APITCH * 128) + addrA[kw][ks][0],
+              const frag5_t af = tr_read8(arow + kh * (APITCH * 128) + addrA[kw][ks][0],
                                          arow + kh * (APITCH * 128) + addrA[kw][ks][1]);
-              acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[kh * 3 + kw], 0, 0, 0);
+              acc[kh * 3 + kw] = WG_MFMA(af, bf, acc[kh * 3 + kw]);
             }
         }
       }
@@ -185,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
           const char* brow = lds_b + tr * 4096;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
-            const bf16x8 af = tr_read8(arow + addrA[0][ks][0], arow + addrA[0][ks][1]);
-            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[tap], 0, 0, 0);
+            const frag5_t bf = tr_read8(brow + addrB[ks][0], brow + addrB[ks][1]);
+            const frag5_t af = tr_read8(arow + addrA[0][ks][0], arow + addrA[0][ks][1]);
+            acc[tap] = WG_MFMA(af, bf, acc[tap]);
           }
         }
       }
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(WgradParams P) {
 // Partial sums: the two groups are added through LDS, then slab[split][tap][ci][co]; the splits are summed in
 // fixed order by wgrad_reduce_kernel.
 struct Wgrad3Params {
-  const bf16* a;      // layer input x
-  const bf16* b;      // dy
+  const u16* a;      // layer input x
+  const u16* b;      // dy
   float* slab;
   int N, H, W, Ca, Cb, lda, ldb;
   int tiles_x, tiles_y, ntiles, nsplit, row_tiles, col_tiles;
@@ -241,6 +245,7 @@ constexpr int W3_STEPS = 10;
 
 __device__ __forceinline__ int swz3(int row) { return ((row >> 1) & 1) << 2; }
 
+template <typename H>
 __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(Wgrad3Params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(512) void wgrad3_bf16_kernel(Wgrad3Params P) {
     const bool next = tile + 1 < t_end && !(P.dbg & 1);   // last tile: the pieces still issue, from the zero page
     stage_tile(next ? tile + 1 : tile);
 
-    bf16x8 fa[2][3], fb[4];
+    frag5_t fa[2][3], fb[4];
     auto load_step = [&](int cc) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -415,6 +420,7 @@ constexpr int W4_BUF = W4_PIECES * 1024;
 constexpr int W4_STEPS = 10;
 constexpr int W4_SLOTS = (W4_PIECES + 7) / 8;         // DMA pieces per wave and tile (8)
 
+template <typename H>
 __global__ __launch_bounds__(512) void wgrad4_bf16_kernel(Wgrad3Params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(512) void wgrad4_bf16_kernel(Wgrad3Params P) {
     const bool next = tile + 1 < t_end && !(P.dbg & 1);
     stage_tile(next ? tile + 1 : tile);
 
-    bf16x8 fa[2][3], fb[4];
+    frag5_t fa[2][3], fb[4];
     auto load_step = [&](int cc) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -581,8 +587,8 @@ __global__ __launch_bounds__(512) void wgrad4_bf16_kernel(Wgrad3Params P) {
 //            images), 8 pieces per wave and tile issued in the first four column steps; the tile barrier sits at the
 //            head of the last column step (12 MFMAs), whose fragment re-reads already target the next buffer.
 struct Wgrad5Params {
-  const bf16* a;      // layer input x
-  const bf16* b;      // dy
+  const u16* a;      // layer input x
+  const u16* b;      // dy
   float* slab;
   int N, H, W, Ca, Cb, lda, ldb;
   int tiles_x, ntiles, nsplit, row_tiles, col_tiles;
@@ -615,7 +621,7 @@ __device__ __forceinline__ frag5_t tr_read8u(int addr0, int addr1, int imm) {
 // TW: tile width in pixel columns.  The x halo's pitch of 7 pixels (odd: bank spreading) holds 5 + 2 columns as well as
 // 4 + 2, so NCO = 128 runs 32 x 5 tiles: the same 30 KiB of halo for 25 % more pixels, 180 MFMAs per wave and barrier
 // instead of 144, and every level of the 959 x 640 pyramid (W + 1 = 960, 480, 240, 120, 60) is a whole number of tiles.
-template <int NCO, int TW>
+template <typename H, int NCO, int TW>
 __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
   constexpr bool WIDE = NCO == 128;
   static_assert(WIDE ? (TW == 4 || TW == 5) : (TW == 4 || TW == 6), "tile widths the LDS layouts are made for");
@@ -845,9 +851,9 @@ __global__ __launch_bounds__(512) void wgrad5_bf16_kernel(Wgrad5Params P) {
             if (bl >= 0 && bl < NBC) {
 #pragma unroll
               for (int co = 0; co < 2; ++co)
-                acc[kh * 3 + kw][ci][co] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, fa[kh][ci]), __builtin_bit_cast(bf16x8, fb[bl % NRING][co]),
-                    acc[kh * 3 + kw][ci][co], 0, 0, 0);
+                acc[kh * 3 + kw][ci][co] = H16<H>::mfma16(__builtin_bit_cast(typename H16<H>::x8, fa[kh][ci]),
+                                                          __builtin_bit_cast(typename H16<H>::x8, fb[bl % NRING][co]),
+                                                          acc[kh * 3 + kw][ci][co]);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -908,8 +914,8 @@ int pick_nsplit3(int ntiles, int npairs) {
 //            (only the tile base and the ragged-edge mask change), one piece between MFMAs
 // Partial sums: slab[split][tap][co][ci], summed in fixed order by the reduce kernels below.
 struct WgradTParams {
-  const bf16* dy;     // up-sampled gradient (channel offset applied)
-  const bf16* x;      // low-res input
+  const u16* dy;     // up-sampled gradient (channel offset applied)
+  const u16* x;      // low-res input
   float* slab;
   int N, H, W;        // low-res grid
   int Co, Ci, lddy, ldx;
@@ -921,6 +927,7 @@ constexpr int WT_ARR = 64 * 128;          // one array
 constexpr int WT_BUF = 6 * WT_ARR;
 constexpr int WT_NBUF = 3;
 
+template <typename H>
 __global__ __launch_bounds__(512) void wgradT_bf16_kernel(WgradTParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1007,8 +1014,8 @@ __global__ __launch_bounds__(512) void wgradT_bf16_kernel(WgradTParams P) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) issue_piece(q, lds0 + k * WT_BUF);
   }
-  bf16x8 fa[2][2][2], fb[2][2][4];                            // [register set][k-step][block]
-  auto read_frags = [&](int bufi, bf16x8 (&a)[2][2], bf16x8 (&b)[2][4]) {
+  frag5_t fa[2][2][2], fb[2][2][4];                            // [register set][k-step][block]
+  auto read_frags = [&](int bufi, frag5_t (&a)[2][2], frag5_t (&b)[2][4]) {
     const char* buf = smem + bufi * WT_BUF + (2 * kg) * 2048;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1346,8 +1353,8 @@ int64_t unetk_wgrad_workspace_bytes(int kind, int n, int h, int w, int c_in, int
 int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
                         int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int accumulate, int dtype,
                         void* stream) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int es = unetk_esize(dtype);
   const int64_t need = unetk_wgrad_workspace_bytes(0, n, h, w, c_in, c_out);
   if (need < 0) return (int)need;
   if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
@@ -1387,7 +1394,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     Wgrad5Params P{};
     P.slab = (float*)workspace;
     P.N = n; P.H = h; P.W = w;
-    P.a = (const bf16*)x; P.b = (const bf16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+    P.a = (const u16*)x; P.b = (const u16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
     UNETK_KNOB(tw6, "UNETK_WGRAD_TW6", 1);     // 0: A/B against 32 x 4 tiles (two columns per group)
     P.tiles_x = host_cdiv(w, tw6 ? 6 : 4);
     P.ntiles = host_cdiv((long)n * (h + 1), 32) * P.tiles_x;
@@ -1395,15 +1402,19 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
     if (tw6) {      // 32 x 6 tiles, three dy columns per group: 36 fragment KiB per 108 MFMAs instead of 28 per 72
       const size_t lds = 2 * ((39 + 28) * 1024) + 9 * 512 * 4;
-      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 6>), lds);
-      hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 6>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+      UNETK_WITH_H(dtype, {
+        UNETK_ALLOW_LDS((wgrad5_bf16_kernel<H, 64, 6>), lds);
+        hipLaunchKernelGGL((wgrad5_bf16_kernel<H, 64, 6>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                          (hipStream_t)stream, P);
+      });
     } else {
 #ifdef UNETK_TUNING
       const size_t lds = 2 * (50 * 1024) + 7 * 512 * 4;
-      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<64, 4>), lds);
-      hipLaunchKernelGGL((wgrad5_bf16_kernel<64, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+      UNETK_WITH_H(dtype, {
+        UNETK_ALLOW_LDS((wgrad5_bf16_kernel<H, 64, 4>), lds);
+        hipLaunchKernelGGL((wgrad5_bf16_kernel<H, 64, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                          (hipStream_t)stream, P);
+      });
 #endif
     }
     UNETK_CHECK_LAUNCH();
@@ -1417,9 +1428,9 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.slab = (float*)workspace;
     P.N = n; P.H = h; P.W = w;
     if (w5_direct) {
-      P.a = (const bf16*)x; P.b = (const bf16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
+      P.a = (const u16*)x; P.b = (const u16*)dy; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
     } else {
-      P.a = (const bf16*)dy; P.b = (const bf16*)x; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
+      P.a = (const u16*)dy; P.b = (const u16*)x; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
     }
     UNETK_KNOB(tw5, "UNETK_WGRAD_TW5", 1);     // 0: A/B against 32 x 4 tiles
     P.tiles_x = host_cdiv(w, tw5 ? 5 : 4);
@@ -1428,15 +1439,19 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.nsplit = pick_nsplit3(P.ntiles, P.row_tiles * P.col_tiles);
     if (tw5) {
       const size_t lds = 2 * ((W5_A_PIECES + 40) * 1024) + 9 * 512 * 4;
-      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128, 5>), lds);
-      hipLaunchKernelGGL((wgrad5_bf16_kernel<128, 5>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+      UNETK_WITH_H(dtype, {
+        UNETK_ALLOW_LDS((wgrad5_bf16_kernel<H, 128, 5>), lds);
+        hipLaunchKernelGGL((wgrad5_bf16_kernel<H, 128, 5>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                          (hipStream_t)stream, P);
+      });
     } else {
 #ifdef UNETK_TUNING      // A/B builds only: the 32 x 4 form is not compiled into the shipped library
       const size_t lds = 2 * W5_BUF + W5_SLOTS * 512 * 4;
-      UNETK_ALLOW_LDS((wgrad5_bf16_kernel<128, 4>), lds);
-      hipLaunchKernelGGL((wgrad5_bf16_kernel<128, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+      UNETK_WITH_H(dtype, {
+        UNETK_ALLOW_LDS((wgrad5_bf16_kernel<H, 128, 4>), lds);
+        hipLaunchKernelGGL((wgrad5_bf16_kernel<H, 128, 4>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                          (hipStream_t)stream, P);
+      });
 #endif
     }
     UNETK_CHECK_LAUNCH();
@@ -1446,7 +1461,7 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
   }
   if (c_out % 128 == 0 && wide) {
     Wgrad3Params P{};
-    P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
+    P.a = (const u16*)x; P.b = (const u16*)dy; P.slab = (float*)workspace;
     P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
     P.tiles_x = host_cdiv(w, 8); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
     P.row_tiles = c_in / 64; P.col_tiles = c_out / 128;
@@ -1456,16 +1471,18 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
       P.dbg = dbg;
     }
     const size_t lds = 2 * W4_BUF;
-    UNETK_ALLOW_LDS((wgrad4_bf16_kernel), lds);
-    hipLaunchKernelGGL(wgrad4_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+    UNETK_WITH_H(dtype, {
+      UNETK_ALLOW_LDS((wgrad4_bf16_kernel<H>), lds);
+      hipLaunchKernelGGL((wgrad4_bf16_kernel<H>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                        (hipStream_t)stream, P);
+    });
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
   Wgrad3Params P{};
-  P.a = (const bf16*)x; P.b = (const bf16*)dy; P.slab = (float*)workspace;
+  P.a = (const u16*)x; P.b = (const u16*)dy; P.slab = (float*)workspace;
   P.N = n; P.H = h; P.W = w; P.Ca = c_in; P.Cb = c_out; P.lda = ldx; P.ldb = lddy;
   P.tiles_x = host_cdiv(w, 16); P.tiles_y = host_cdiv(h, 16); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.row_tiles = c_in / 64; P.col_tiles = c_out / 64;
@@ -1475,9 +1492,11 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
     P.dbg = dbg;
   }
   const size_t lds = 2 * W3_BUF;
-  UNETK_ALLOW_LDS((wgrad3_bf16_kernel), lds);
-  hipLaunchKernelGGL(wgrad3_bf16_kernel, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
+  UNETK_WITH_H(dtype, {
+    UNETK_ALLOW_LDS((wgrad3_bf16_kernel<H>), lds);
+    hipLaunchKernelGGL((wgrad3_bf16_kernel<H>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(512), lds,
                      (hipStream_t)stream, P);
+  });
   UNETK_CHECK_LAUNCH();
   const long total = 9L * c_in * c_out;
   launch_wgrad_reduce((const float*)workspace, dw, P.nsplit, 9, c_in, c_out, accumulate, (hipStream_t)stream);
@@ -1488,8 +1507,8 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
 int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int dy_choff, float* dw, void* workspace,
                          int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int hs, int ws, int pad_t,
                          int pad_l, int accumulate, int dtype, void* stream) {
-  if (dtype != UNETK_BF16 && dtype != UNETK_F32) return UNETK_ERR_DTYPE;
-  const int es = dtype == UNETK_BF16 ? 2 : 4;
+  if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
+  const int es = unetk_esize(dtype);
   const int64_t need = unetk_wgrad_workspace_bytes(1, n, h, w, c_in, c_out);
   if (need < 0) return (int)need;
   if (!x || !dy || !dw || !workspace || workspace_bytes < need) return UNETK_ERR_ARG;
@@ -1520,32 +1539,36 @@ int unetk_convT2x2_wgrad(const void* x, int ldx, const void* dy, int lddy, int d
     if ((int64_t)hs * ws * lddy * 2 >= (int64_t)1 << 32 || (int64_t)h * w * ldx * 2 >= (int64_t)1 << 32)
       return UNETK_ERR_SHAPE;                                  // 32-bit DMA offsets inside an image
     WgradTParams T{};
-    T.dy = (const bf16*)dy + dy_choff; T.x = (const bf16*)x; T.slab = (float*)workspace;
+    T.dy = (const u16*)dy + dy_choff; T.x = (const u16*)x; T.slab = (float*)workspace;
     T.N = n; T.H = h; T.W = w; T.Co = c_out; T.Ci = c_in; T.lddy = lddy; T.ldx = ldx;
     T.Hs = hs; T.Ws = ws; T.padT = pad_t; T.padL = pad_l;
     T.tiles_x = host_cdiv(w, 32); T.tiles_y = host_cdiv(h, 2); T.ntiles = n * T.tiles_x * T.tiles_y;
     T.row_tiles = c_out / 64; T.col_tiles = c_in / 128;
     T.nsplit = pick_nsplit3(T.ntiles, T.row_tiles * T.col_tiles);
     const size_t ldst = (size_t)WT_NBUF * WT_BUF;
-    UNETK_ALLOW_LDS((wgradT_bf16_kernel), ldst);
-    hipLaunchKernelGGL(wgradT_bf16_kernel, dim3(T.row_tiles * T.col_tiles * T.nsplit), dim3(512), ldst,
+    UNETK_WITH_H(dtype, {
+      UNETK_ALLOW_LDS((wgradT_bf16_kernel<H>), ldst);
+      hipLaunchKernelGGL((wgradT_bf16_kernel<H>), dim3(T.row_tiles * T.col_tiles * T.nsplit), dim3(512), ldst,
                        (hipStream_t)stream, T);
+    });
     UNETK_CHECK_LAUNCH();
     launch_wgrad_reduce((const float*)workspace, dw, T.nsplit, 4, c_out, c_in, accumulate, (hipStream_t)stream);
     UNETK_CHECK_LAUNCH();
     return UNETK_OK;
   }
   WgradParams P{};
-  P.a = (const bf16*)dy + dy_choff; P.b = (const bf16*)x; P.slab = (float*)workspace;
+  P.a = (const u16*)dy + dy_choff; P.b = (const u16*)x; P.slab = (float*)workspace;
   P.N = n; P.H = h; P.W = w; P.Ca = c_out; P.Cb = c_in; P.lda = lddy; P.ldb = ldx;
   P.Ha = hs; P.Wa = ws; P.padT = pad_t; P.padL = pad_l;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.row_tiles = c_out / 64; P.col_tiles = c_in / 64;
   P.nsplit = pick_nsplit(P.ntiles, P.row_tiles * P.col_tiles);
   const size_t lds = 10 * 36 * 128 + 256 * 128;
-  UNETK_ALLOW_LDS((wgrad_bf16_kernel<1>), lds);
-  hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
+  UNETK_WITH_H(dtype, {
+    UNETK_ALLOW_LDS((wgrad_bf16_kernel<H, 1>), lds);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<H, 1>), dim3(P.row_tiles * P.col_tiles * P.nsplit), dim3(256), lds,
                      (hipStream_t)stream, P);
+  });
   UNETK_CHECK_LAUNCH();
   // rows = co, cols = ci ; parameter layout [Ci][Co][2][2]
   const long total = 4L * c_in * c_out;

@@ -2,7 +2,8 @@
 
     evaluate(net, dataloader, device, amp) -> mean Dice over the validation batches (a 0-dim tensor)
 
-Same control flow as the reference: eval mode, inference_mode, autocast (bf16 -- the kernels implement bf16/fp32),
+Same control flow as the reference: eval mode, inference_mode, autocast (`amp_dtype`: bf16 by default, as
+BASELINE.json's configurations; torch.float16 is what the reference's bare `torch.autocast(device.type)` picks on a GPU),
 per batch the forward pass and the Dice score, train mode restored at the end.  For n_classes > 1 the reference's
 one_hot(argmax) -> one_hot(mask) -> multiclass_dice_coeff(..[:, 1:]) chain (evaluate.py:31-36, five full-size fp32
 temporaries) is ONE counting pass over the logits and the int64 mask (unetk_eval_dice).  The n_classes == 1 branch
@@ -38,10 +39,10 @@ def _score_multiclass(logits, labels, n_classes):
 
 
 @torch.inference_mode()
-def evaluate(net, dataloader, device, amp):
+def evaluate(net, dataloader, device, amp, amp_dtype=torch.bfloat16):
     net.eval()
     total, n_batches = 0, len(dataloader)
-    with torch.autocast(device.type, dtype=torch.bfloat16, enabled=amp):
+    with torch.autocast(device.type, dtype=amp_dtype, enabled=amp):
         for sample in dataloader:
             frames = sample['image'].to(device=device, dtype=torch.float32, memory_format=torch.channels_last)
             labels = sample['mask'].to(device=device, dtype=torch.long)

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UNETK_LIB') or os.path.join(os.path.dirname(_HERE), 'libunetk.so')   # UNETK_LIB: perf A/B builds
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
 STAT_REPLICAS = 32
 
 _ERR = {-1: 'unsupported shape/pitch/channel count', -2: 'unsupported dtype', -3: 'misaligned pointer or pitch',
@@ -77,7 +77,9 @@ def dtype_code(dt):
         return BF16
     if dt == torch.float32:
         return F32
-    raise RuntimeError(f'unetk kernels support bfloat16 and float32 activations, got {dt}')
+    if dt == torch.float16:
+        return F16
+    raise RuntimeError(f'unetk kernels support bfloat16, float16 and float32 activations, got {dt}')
 
 
 def stream_ptr():
@@ -136,7 +138,7 @@ class KernelTimer:
         if pos is None:
             return None
         n_gemm, dtype = a[pos[0]], a[pos[1]]
-        if dtype != BF16:
+        if dtype == F32:
             return 'conv3x3_db_kernel'
         return 'conv3x3_k32_kernel' if n_gemm % 128 == 0 else 'conv3x3_k32n64_kernel'
 
@@ -148,7 +150,7 @@ class KernelTimer:
         if pos is None:
             return 0.0
         n, h, w, c_in, c_out = a[pos[0]:pos[0] + 5]
-        es = 2 if a[pos[1]] == BF16 else 4
+        es = 4 if a[pos[1]] == F32 else 2
         return float(es) * (n * h * w * (c_in + c_out) + 9 * c_in * c_out)
 
     # HBM-bound families: name -> (family, algorithmic bytes) from the call's arguments (positions follow
@@ -157,7 +159,7 @@ class KernelTimer:
     @staticmethod
     def _hbm(name, a):
         def es(code):
-            return 2 if code == BF16 else 4
+            return 4 if code == F32 else 2
         if name == 'unetk_bn_relu_apply':                     # read z, write act
             return 'bn_apply', 2.0 * a[6] * a[7] * es(a[8])
         if name == 'unetk_bn_relu_apply_pool':                # + the pooled tensor

@@ -27,13 +27,14 @@ FUSE_EVAL_EPILOGUE = True
 
 
 def activation_dtype(x):
-    """bf16 under torch.autocast (the reference's --amp path, train.py:100), otherwise the input's dtype."""
+    """The autocast dtype under torch.autocast (the reference's --amp path, train.py:100: torch's default for 'cuda' is
+    float16, BASELINE.json's configurations ask for bfloat16), otherwise the input's dtype."""
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype('cuda')
-        if dt != torch.bfloat16:
-            raise RuntimeError('the MI355X kernels implement bf16 and fp32; use torch.autocast(dtype=torch.bfloat16)')
+        if dt not in (torch.bfloat16, torch.float16):
+            raise RuntimeError(f'the MI355X kernels implement bf16, fp16 and fp32; autocast dtype {dt} is not supported')
         return dt
-    if x.dtype in (torch.float32, torch.bfloat16):
+    if x.dtype in (torch.float32, torch.bfloat16, torch.float16):
         return x.dtype
     raise RuntimeError(f'unsupported activation dtype {x.dtype}')
 
@@ -140,7 +141,7 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     batch_stats = _bn_uses_batch_stats(bn)
     n, h, w, _, _ = ops.nhwc_meta(x, 'conv input')
     stats = ops.new_stats(c_out, x.device) if batch_stats else None
-    if not batch_stats and FUSE_EVAL_EPILOGUE and not SAVING_FOR_BACKWARD and (c_in <= 4 or dtype == torch.bfloat16):
+    if not batch_stats and FUSE_EVAL_EPILOGUE and not SAVING_FOR_BACKWARD and (c_in <= 4 or dtype != torch.float32):
         # inference (evaluate.py:10, predict.py:20 call net.eval()): BatchNorm with running statistics is a per-channel
         # affine map -> folded with the ReLU into the conv epilogue, no pre-BN tensor, no second pass
         st = ops.BNState(c_out, x.device)

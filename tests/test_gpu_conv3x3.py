@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 # fp32: BASELINE.json's 1e-4 relative; bf16: 2e-2 relative (inputs are pre-rounded to bf16, so the
 # only error left is accumulation order + one output rounding, far inside that budget).
-TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+# fp16: three more mantissa bits than bf16 -> 3e-3.
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 3e-3}
+ALL = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def _rand(shape, seed, scale=1.0):
@@ -18,7 +20,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.rand(shape, generator=g) * 2 - 1) * scale
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', ALL)
 @pytest.mark.parametrize('n,h,w,cin,cout', [
     (1, 8, 32, 64, 64),        # exactly one tile
     (2, 16, 23, 64, 128),      # ragged width (the 959 -> 479 -> ... case), two n-tiles
@@ -46,7 +48,7 @@ def test_conv3x3_fprop_and_stats(dtype, n, h, w, cin, cout):
     assert np.allclose(s[:, 1], (g64 * g64).sum(0), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', ALL)
 def test_conv3x3_fprop_channel_slices(dtype):
     """Input read from, and output written into, channel slices of wider NHWC buffers (the concat trick)."""
     from oracle import ops_numpy as O
@@ -63,7 +65,7 @@ def test_conv3x3_fprop_channel_slices(dtype):
     assert torch.all(yb[..., :64] == 7.0) and torch.all(yb[..., 128:] == 7.0)   # neighbours untouched
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', ALL)
 @pytest.mark.parametrize('n,h,w,cin,cout', [(2, 16, 23, 64, 128), (1, 9, 40, 128, 64)])
 def test_conv3x3_dgrad(dtype, n, h, w, cin, cout):
     from oracle import ops_numpy as O
@@ -99,7 +101,7 @@ class _State:
         self.shift = (beta.cuda() - self.mean * self.scale)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', ALL)
 @pytest.mark.parametrize('n,h,w,cin,cout', [
     (1, 16, 32, 64, 64),        # one tile of the 64-channel kernel (bf16: the pipelined k32 kernel, weights resident)
     (2, 37, 75, 64, 64),        # ragged both ways, several tiles per workgroup

@@ -316,3 +316,114 @@ def test_gradient_wrt_the_input_image_matches_torch(amp):
         cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r)))
         assert cos > 0.75, cos
         assert 0.5 < np.linalg.norm(g) / np.linalg.norm(r) < 2.0
+
+
+# ------------------------------------------------------------------------------------------------ fp16 (the reference's
+# `--amp` on a GPU: train.py:100 leaves autocast's dtype at torch's default, float16, and train.py:80,114-117 wrap the
+# step in a GradScaler).  Same kernels as bf16 with the f16 MFMA / dot instructions; three more mantissa bits.
+def test_fp16_autocast_on_separated_logits():
+    from unet import UNet
+    g = golden(TAG)
+    img = _img()
+    net = _closed_form(UNet(3, 2, False), g['bias_train']).cuda().train()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        zh = net(img)
+    assert zh.dtype == torch.float16
+    assert float((npy(zh).argmax(1) == g['logits_train'].argmax(1)).mean()) >= 0.999
+    # fp16 rounds 8x finer than bf16: the train-mode bar that bf16 meets only in the L2 sense holds here in the max sense
+    # (measured: 4.1e-3 max-relative, 2.2e-3 L2; bf16 on the same fixture: 2.9e-2 / 1.7e-2)
+    assert rel_err(npy(zh), g['logits_train']) <= 1e-2
+    assert l2_err(npy(zh), g['logits_train']) <= 5e-3
+    with torch.no_grad():
+        net.outc.conv.bias.copy_(torch.from_numpy(g['bias_eval']).cuda())
+    net.eval()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        eh = net(img)
+    assert float((npy(eh).argmax(1) == g['logits_eval'].argmax(1)).mean()) >= 0.999
+    assert rel_err(npy(eh), g['logits_eval']) <= 2e-3            # measured 7e-4 (bf16: 5.2e-3)
+
+
+def _reference_loop_body_with_scaler(model, optimizer, grad_scaler, criterion, images, true_masks, amp, dice_loss,
+                                     gradient_clipping=1.0):
+    """train.py:100-117 as written, GradScaler included; autocast's dtype is left at torch's default (float16)."""
+    with torch.autocast(images.device.type if images.device.type != 'mps' else 'cpu', enabled=amp):
+        masks_pred = model(images)
+        loss = criterion(masks_pred, true_masks)
+        loss += dice_loss(F.softmax(masks_pred, dim=1).float(),
+                          F.one_hot(true_masks, model.n_classes).permute(0, 3, 1, 2).float(), multiclass=True)
+    optimizer.zero_grad(set_to_none=True)
+    grad_scaler.scale(loss).backward()
+    grad_scaler.unscale_(optimizer)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clipping)
+    grad_scaler.step(optimizer)
+    grad_scaler.update()
+    return loss.detach()
+
+
+def test_literal_reference_train_loop_with_grad_scaler_fp16():
+    """The reference's `--amp` step exactly as train.py writes it -- default-dtype autocast (fp16) and GradScaler --
+    through unet.UNet, against the CPU oracle's fp32 train_step on identical weights and data."""
+    from oracle.unet_torch import TorchUNet, train_step
+    from unet import UNet
+    from utils.dice_score import dice_loss
+    shape = (2, 3, 64, 80)
+    img = torch.from_numpy(W.wave('a14.img', shape, 0.5, 0.5))
+    mask = torch.from_numpy(W.int_wave('a14.mask', (2, 64, 80), 2))
+    lr = 1e-3
+    ref = _closed_form(TorchUNet(3, 2, False)).train()
+    p0 = {k: v.detach().clone() for k, v in ref.named_parameters()}
+    ropt = torch.optim.RMSprop(ref.parameters(), lr=lr, weight_decay=1e-8, momentum=0.999, foreach=True)
+    rloss = train_step(ref, ropt, img, mask)
+
+    net = _closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train()
+    opt = torch.optim.RMSprop(net.parameters(), lr=lr, weight_decay=1e-8, momentum=0.999, foreach=True)
+    scaler = torch.amp.GradScaler('cuda', enabled=True)
+    loss = _reference_loop_body_with_scaler(net, opt, scaler, torch.nn.CrossEntropyLoss(),
+                                            img.cuda().to(memory_format=torch.channels_last), mask.cuda(), True, dice_loss)
+    assert abs(float(loss) - float(rloss.detach())) < 5e-3
+    assert float(scaler.get_scale()) == 65536.0          # no overflow: the step was taken, the scale kept
+    got, rp = dict(net.named_parameters()), dict(ref.named_parameters())
+    for k in ('outc.conv.weight', 'outc.conv.bias', 'up4.conv.double_conv.3.weight', 'up4.conv.double_conv.4.weight',
+              'up4.up.weight', 'up4.up.bias'):
+        du = npy(got[k]) - p0[k].numpy()
+        dr = rp[k].detach().numpy() - p0[k].numpy()
+        wgt = np.abs(rp[k].grad.numpy())
+        same = float(((np.sign(du) == np.sign(dr)) * wgt).sum() / wgt.sum())
+        assert same >= 0.98, (k, same)                   # (bf16: 0.97 -- see test_literal_reference_train_loop_runs_unchanged)
+        assert abs(np.abs(du).mean() / np.abs(dr).mean() - 1) < 2e-2, k
+    for k in ('outc.conv.weight', 'outc.conv.bias', 'up4.conv.double_conv.4.bias'):
+        assert l2_err(npy(got[k].grad), rp[k].grad.numpy()) < 2e-2, k     # unscaled and clipped, as the oracle's
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())))
+    assert total <= 1.0 + 1e-4
+
+
+def test_trainer_fp16_scales_the_loss_and_skips_a_step_on_overflow():
+    """Trainer(amp_dtype=torch.float16): same step as the bf16 trainer within fp16/bf16 rounding; with an absurd loss
+    scale the fp16 gradients overflow, GradScaler finds the inf in the flat buffer, the fused optimizer step is skipped
+    (parameters bit-identical) and the scale is halved."""
+    from unet import UNet
+    from unetk.trainer import Trainer
+    img = _img()
+    mask = torch.from_numpy(W.int_wave(TAG + '.mask', (SHAPE[0],) + SHAPE[2:], 2)).cuda()
+    nets = [_closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train() for _ in range(3)]
+    th = Trainer(nets[0], learning_rate=1e-3, amp_dtype=torch.float16)
+    t32 = Trainer(nets[1], learning_rate=1e-3, amp=False)
+    assert th.grad_scaler.is_enabled() and not t32.grad_scaler.is_enabled()
+    b0 = nets[0].outc.conv.bias.detach().clone()
+    lh, l32 = float(th.step(img, mask)), float(t32.step(img, mask))
+    assert abs(lh - l32) < 5e-3 * abs(l32)
+    assert float(th.grad_scaler.get_scale()) == 65536.0
+    n_h, n_32 = float(th.optimizer.total_norm), float(t32.optimizer.total_norm)
+    assert abs(n_h / n_32 - 1) < 3e-2                    # the norm the clip saw is the UNSCALED one
+    assert not torch.equal(nets[0].outc.conv.bias.detach(), b0)       # the step was taken
+    assert th.optimizer._steps == 1
+    # ---- overflow
+    to = Trainer(nets[2], learning_rate=1e-3, amp_dtype=torch.float16)
+    to.grad_scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 60)
+    before = {k: v.detach().clone() for k, v in nets[2].named_parameters()}
+    lo = float(to.step(img, mask))
+    assert np.isfinite(lo)                                # the forward is not scaled
+    assert float(to.grad_scaler.get_scale()) == 2.0 ** 59
+    for k, v in nets[2].named_parameters():
+        assert torch.equal(v.detach(), before[k]), k
+    assert to.optimizer._steps == 0
