@@ -66,7 +66,7 @@ CONFIGS = {
                          workload='UNet(3,21,bilinear=False) fp32 training step, CE+dice multiclass, batch {B} per GPU '
                                   '(BASELINE.json configs[4]; batch size not given there)'),
 }
-PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # MI355X_MICROARCH.md: dense bf16 MFMA; fp32-input MFMA
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'f32': 157.3}      # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA; fp32-input MFMA
 
 
 def parse_args(argv=None):
@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--dry', action='store_true', help='CPU rehearsal of the rank plumbing; no kernels, no measurement')
+    ap.add_argument('--amp-dtype', choices=['bf16', 'fp16'], default='bf16',
+                    help="autocast dtype of the amp configurations: bf16 (BASELINE.json) or fp16 (the reference's --amp "
+                         "default on a GPU, run with its GradScaler); not the headline line")
     ap.add_argument('--force-collectives', action='store_true',
                     help='N = 1: all-reduce the gradient buckets in a 1-rank RCCL group anyway (overhead measurement)')
     return ap.parse_args(argv)
@@ -231,7 +234,8 @@ def main(argv=None):
     cfg = CONFIGS[args.config]
     B = args.batch_size or cfg['batch']
     hh, ww = args.height or cfg['h'], args.width or cfg['w']
-    dtype_name = 'bf16' if cfg['amp'] else 'f32'
+    dtype_name = ('fp16' if args.amp_dtype == 'fp16' else 'bf16') if cfg['amp'] else 'f32'
+    amp_dtype = torch.float16 if dtype_name == 'fp16' else torch.bfloat16
 
     if args.dry:
         if args.backend != 'gloo':
@@ -278,13 +282,13 @@ def main(argv=None):
         masks = torch.randint(0, cfg['n_classes'], (B, hh, ww), device=dev, generator=g)
 
     if cfg['train']:
-        trainer = Trainer(net, amp=cfg['amp'], force_collectives=args.force_collectives)
+        trainer = Trainer(net, amp=cfg['amp'], force_collectives=args.force_collectives, amp_dtype=amp_dtype)
 
         def step():
             return trainer.step(images, masks)
     else:
         def step():
-            with torch.inference_mode(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=cfg['amp']):
+            with torch.inference_mode(), torch.autocast('cuda', dtype=amp_dtype, enabled=cfg['amp']):
                 return net(images)
 
     for _ in range(args.warmup):
@@ -381,14 +385,14 @@ def main(argv=None):
 
     if rank == 0:
         ips = world * B * args.steps / elapsed
-        sized = (hh, ww) == (cfg['h'], cfg['w'])
+        sized = (hh, ww) == (cfg['h'], cfg['w']) and dtype_name != 'fp16'     # the metric is quoted in bf16 / fp32
         out = {
             'metric': cfg['metric'] if sized else f'images/sec @{ww}x{hh} {dtype_name}', 'value': ips,
             'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_name, 'data': 'synthetic',
             'config': {'workload': cfg['workload'].format(B=B) if sized else
-                       f'{args.config} at {ww}x{hh}, batch {B} per GPU (sanity run)',
+                       f'{args.config} at {ww}x{hh} {dtype_name}, batch {B} per GPU (not the headline configuration)',
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'optimizer': 'RMSprop+clip_grad_norm' if cfg['train'] else None,
                        'loss': 'CE+dice' if cfg['train'] else None},
