@@ -39,6 +39,9 @@
 #ifndef UNETK_K32_DSTEPS
 #define UNETK_K32_DSTEPS 0   /* k-steps of a tile's first stage that carry its DMA pieces (0: 4) */
 #endif
+#ifndef UNETK_K32_BNR_DEFER
+#define UNETK_K32_BNR_DEFER 8
+#endif
 #ifndef UNETK_K32_FIRSTC
 #define UNETK_K32_FIRSTC 0
 #endif
@@ -544,13 +547,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32_kernel(ConvParams P) {
 //
 // EPI: 0 plain store; 1 BatchNorm statistics of the output (forward); 2 (dgrad) the BN-backward sums of the layer that
 // produced this tensor (ConvParams::bn_z): that layer's z at the tile's pixels is fetched during the tile's LAST stage
-// -- into the registers the packed previous tile occupied until its stores went out in the first stage -- and the
-// masked sums are formed at the hand-over from the rounded values.
+// and the masked sums are formed from it and the rounded values under the MFMAs of the NEXT tile's first stage.
 template <typename H, bool WRES, int EPI>
 __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   typedef typename H16<H>::x2 h2;
   typedef typename H16<H>::x8 h8;
   constexpr bool STATS = EPI == 1, BNR = EPI == 2;
+  constexpr int BNR_DEFER = UNETK_K32_BNR_DEFER;             // units (of 16) whose masked sums ride under the next tile
   constexpr int NB16 = 4, NW = 8, MB = 2, TR = MB * NW, HP = 34, NP = 4, TAPS = 9;
   constexpr int NPIX = (TR + 2) * HP;
   constexpr int IN_INSTR = (NPIX * NP + 63) / 64;            // 39 one-KiB DMA pieces
@@ -715,13 +718,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int curi = 0, curw = 0;
 
-  // BNR: z of the producer layer for the tile in flight, [row][pixel set][pixel] x 4 adjacent channels (packed), and
-  // that layer's per-channel coefficients (re-fetched with every tile: they are not worth 12 registers for a whole launch)
+  // BNR: z of the producer layer at the tile's pixels, [row][pixel set][pixel] x 4 adjacent channels (packed)
   unsigned zr[BNR ? MB : 1][2][4][2];
-  float* bn_coef = reinterpret_cast<float*>(smem + 2 * IN_BYTES + 2 * W_BYTES);   // [3][64]: scale, shift, mean
-  if constexpr (BNR) {
-    if (tid < 3 * BN) bn_coef[tid] = (tid < BN ? P.bn_scale : tid < 2 * BN ? P.bn_shift - BN : P.bn_mean - 2 * BN)[tid];
-  }
   auto fetch_z = [&](int tile) {
     const int img = tile / tiles_per_img, rem = tile - img * tiles_per_img;
     const int y0 = (rem / P.tiles_x) * TR, x0 = (rem % P.tiles_x) * 32;
@@ -741,6 +739,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
           zr[mb][ps][i][0] = r[0];
           zr[mb][ps][i][1] = r[1];
         }
+    }
+  };
+
+  // BNR: the masked sums of the PENDING tile (its rounded values sit in pk until their stores went out, its z in zr
+  // until the next fetch in this tile's last stage) are formed under the MFMAs of the next tile's first stage, one
+  // (row, pixel set, pixel) unit of four channels per slot: done at the hand-over, with every wave at once and no MFMA
+  // in flight, they cost 0.23 of the 0.95 ms of a 64 -> 64 launch at 16 x 640 x 959.
+  // Registers: pk and zr are both live through a first stage (+32 over the hand-over version), so the lane keeps only
+  // scale and shift of its four channels; the second sum is accumulated as sum dz * z and turned into
+  // sum dz * (z - mean) at the very end (- mean * sum dz: exact bf16 products and fp32 accumulation either way).
+  float bsc[NB16], bsh[NB16];
+  if constexpr (BNR) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zr[mb][ps][i][0] = zr[mb][ps][i][1] = 0u;
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) { bsc[cb] = P.bn_scale[NB16 * c16 + cb]; bsh[cb] = P.bn_shift[NB16 * c16 + cb]; }
+  }
+  auto emit_bnr = [&](int u) {
+    const int mb = u >> 3, ps = (u >> 2) & 1, i = u & 3;
+    const bool inside = st_xl + 4 * ps + i < st_wlim[mb];
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) {
+      const unsigned zw = zr[mb][ps][i][cb >> 1], dw = pk[mb][ps][cb][i >> 1];
+      const float z = (cb & 1) ? H16<H>::hi(zw) : H16<H>::lo(zw);
+      const float f = (i & 1) ? H16<H>::hi(dw) : H16<H>::lo(dw);
+      const float dz = (inside && fmaf(z, bsc[cb], bsh[cb]) > 0.f) ? f : 0.f;
+      tsum[cb] += dz;
+      tsq[cb] = fmaf(dz, z, tsq[cb]);
     }
   };
 
@@ -795,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
     int a_base = (int)(lds0 + curi * IN_BYTES) + (p00 << 6), a_next = (int)(lds0 + (curi ^ 1) * IN_BYTES) + (p00 << 6);
     int w_base = (int)(ldsw0 + widx * W_BYTES) + lane * 16, w_next = (int)(ldsw0 + widx_next * W_BYTES) + lane * 16;
     asm volatile("" : "+v"(a_base), "+v"(a_next), "+v"(w_base), "+v"(w_next));   // keep tap / fragment offsets immediate
-    const bool keep_stores = FIRST && st_all16;
+    const bool keep_stores = FIRST && st_all16 && !BNR;      // BNR interleaves its stores with the DMA pieces
     // slots (k-step t, A fragment ag) with t < 8, ag < 3: 24 per stage.  A first stage issues its DMA pieces in the
     // first DSTEPS k-steps and the 16 pending stores behind them (so that the stores are the youngest vector-memory
     // operations and the barrier's vmcnt(16) waits for the DMA only); other stages spread the pieces over all 24 slots.
@@ -840,7 +870,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
             // statistics of the previous tile, group t: channels {0,1}, {2}, {3} behind A fragments 0, 1, 2
             if (t < 4 && !(UNETK_K32_ABL & 1)) emit_stats(t, ag == 0 ? 0 : ag + 1, ag + 2);
           }
-          if constexpr (FIRST) {
+          if constexpr (FIRST && BNR) {
+            // masked BN-backward sums of the previous tile, one unit per slot, each followed by the store of the same
+            // pixel: pk and zr are released unit by unit while the first k-step is still defining the accumulators
+            // (both held through the whole stage do not fit 256 registers)
+            if (sl < 16) {
+              if (sl >= 16 - BNR_DEFER && !(UNETK_K32_ABL & 8)) emit_bnr(sl);
+              emit_store(sl);
+            }
+          } else if constexpr (FIRST) {
             // the 16 stores of the previous tile: store k goes into slot 3 * DSTEPS + k * SSLOTS / 16
 #pragma unroll
             for (int k = 0; k < 16; ++k)
@@ -892,37 +930,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
           rnd[cb][0] = __builtin_bit_cast(unsigned, lo);
           rnd[cb][1] = __builtin_bit_cast(unsigned, hi);
         }
-        if constexpr (BNR && !(UNETK_K32_ABL & 8)) {
-          float bsc[NB16], bsh[NB16], bmu[NB16];              // read per group: 12 registers only while they are used
 #pragma unroll
-          for (int cb = 0; cb < NB16; ++cb) {
-            bsc[cb] = bn_coef[NB16 * c16 + cb]; bsh[cb] = bn_coef[BN + NB16 * c16 + cb]; bmu[cb] = bn_coef[2 * BN + NB16 * c16 + cb];
-          }
+        for (int cb = 0; cb < NB16; ++cb) { pk[mb][ps][cb][0] = rnd[cb][0]; pk[mb][ps][cb][1] = rnd[cb][1]; }
+        if constexpr (BNR) {
+          // the units that are not deferred (their z registers are free again before the next tile starts)
+          if (!(UNETK_K32_ABL & 8)) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            // (fence: the scheduler otherwise unpacks all 64 values of the tile up front and the allocator spills --
-            // scratch reloads with vmcnt(0) waits, which also wait for the next stage's DMA)
-            __builtin_amdgcn_sched_barrier(0);
-            const bool inside = st_xl + 4 * ps + i < st_wlim[mb];
-#pragma unroll
-            for (int cb = 0; cb < NB16; ++cb) {
-              const unsigned zw = zr[mb][ps][i][cb >> 1], dw = rnd[cb][i >> 1];
-              const float z = (cb & 1) ? H16<H>::hi(zw) : H16<H>::lo(zw);
-              const float f = (i & 1) ? H16<H>::hi(dw) : H16<H>::lo(dw);
-              const float dz = (inside && fmaf(z, bsc[cb], bsh[cb]) > 0.f) ? f : 0.f;
-              tsum[cb] += dz;
-              tsq[cb] = fmaf(dz, z - bmu[cb], tsq[cb]);
+            for (int i = 0; i < 4; ++i) {
+              if (mb * 8 + ps * 4 + i < 16 - BNR_DEFER) {
+                __builtin_amdgcn_sched_barrier(0);   // (unfenced, all values of the tile are unpacked up front: spills)
+                emit_bnr(mb * 8 + ps * 4 + i);
+              }
             }
           }
         }
-#pragma unroll
-        for (int cb = 0; cb < NB16; ++cb) { pk[mb][ps][cb][0] = rnd[cb][0]; pk[mb][ps][cb][1] = rnd[cb][1]; }
       }
   }
   // the last tile's statistics and stores
   if constexpr (STATS) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) emit_stats(g);
+  }
+  if constexpr (BNR) {
+    if (!(UNETK_K32_ABL & 8)) {
+#pragma unroll
+      for (int u = 16 - BNR_DEFER; u < 16; ++u) emit_bnr(u);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 16; ++k) emit_store(k);
@@ -948,17 +981,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_k32n64_kernel(ConvParams P) {
       float v = 0;
 #pragma unroll
       for (int w8 = 0; w8 < NW; ++w8) v += part[w8 * 2 * BN + tid];
+      double vd = (double)v;
       if constexpr (BNR) {
-        if (tid & 1) v *= P.bn_invstd[tid >> 1];              // sum dz (z - mean)  ->  sum dz xhat
+        if (tid & 1) {                                          // sum dz z  ->  sum dz (z - mean)  ->  sum dz xhat
+          float s1 = 0;
+#pragma unroll
+          for (int w8 = 0; w8 < NW; ++w8) s1 += part[w8 * 2 * BN + tid - 1];
+          vd = (vd - (double)P.bn_mean[tid >> 1] * (double)s1) * (double)P.bn_invstd[tid >> 1];
+        }
       }
       double* dst = P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout) * 2 + tid;
-      unsafeAtomicAdd(dst, (double)v);
+      unsafeAtomicAdd(dst, vd);
     }
   }
 }
 
 template <typename H, bool WRES, int EPI> int launch_k32n64(const ConvParams& P, hipStream_t s) {
-  constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024) + (EPI == 2 ? 1024 : 0);
+  constexpr size_t lds = 2 * (39 * 1024) + 2 * (36 * 1024);
   UNETK_ALLOW_LDS((conv3x3_k32n64_kernel<H, WRES, EPI>), lds);
   ConvParams Q = P;
   Q.tiles_x = host_cdiv(P.W, 32);
