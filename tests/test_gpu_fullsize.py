@@ -15,6 +15,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+H16 = [torch.bfloat16, torch.float16]      # both 16-bit element types run the same kernels (csrc/common.h: H16<T>)
+
 
 def _ints(shape, seed, density=1.0):
     g = torch.Generator().manual_seed(seed)
@@ -40,15 +42,16 @@ CONV_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize('dt16', H16)
 @pytest.mark.parametrize('n,h,w,cin,cout', CONV_SHAPES)
-def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout):
+def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout, dt16):
     from unetk import ops
-    dens = min(1.0, 24.0 / (9 * cin))                   # ~24 non-zero taps per output: |y| <= 256, exact in bf16
+    dens = min(1.0, 24.0 / (9 * cin))                   # ~24 non-zero taps per output: |y| <= 256, exact in bf16 and fp16
     x = _ints((n, h, w, cin), 1).cuda()
     wt = _ints((cout, cin, 3, 3), 2, dens).cuda()
-    xb = x.bfloat16()
+    xb = x.to(dt16)
     stats = ops.new_stats(cout, 'cuda')
-    y = ops.conv3x3_fprop(xb, ops.pack_weight(0, wt, cout, cin, torch.bfloat16), cout, stats=stats)
+    y = ops.conv3x3_fprop(xb, ops.pack_weight(0, wt, cout, cin, dt16), cout, stats=stats)
     wmat = wt.reshape(cout, cin * 9).t().contiguous()
     s1 = torch.zeros(cout, dtype=torch.float64, device='cuda')
     s2 = torch.zeros(cout, dtype=torch.float64, device='cuda')
@@ -65,7 +68,7 @@ def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout):
     dy = _ints((n, h, w, cout), 3).cuda()
     dens_d = min(1.0, 24.0 / (9 * cout))
     wd = _ints((cout, cin, 3, 3), 4, dens_d).cuda()
-    dx = ops.conv3x3_dgrad(dy.bfloat16(), ops.pack_weight(1, wd, cout, cin, torch.bfloat16), cin)
+    dx = ops.conv3x3_dgrad(dy.to(dt16), ops.pack_weight(1, wd, cout, cin, dt16), cin)
     wrot = wd.flip(2, 3).permute(1, 0, 2, 3).reshape(cin, cout * 9).t().contiguous()
     for i in range(n):
         ref = (_im2col(dy[i:i + 1]) @ wrot).reshape(h, w, cin)
@@ -73,7 +76,7 @@ def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout):
 
     # wgrad: dw[co,ci,kh,kw] = sum_pixels x[p + tap][ci] * dy[p][co]  (integers < 2^24: exact in fp32)
     dw = torch.empty((cout, cin, 3, 3), device='cuda')
-    ops.conv3x3_wgrad(xb, dy.bfloat16(), dw)
+    ops.conv3x3_wgrad(xb, dy.to(dt16), dw)
     ref = torch.zeros((cout, cin * 9), device='cuda')
     for i in range(n):
         ref += dy[i].reshape(h * w, cout).t() @ _im2col(x[i:i + 1])
@@ -81,16 +84,17 @@ def test_conv3x3_fprop_stats_dgrad_wgrad_exact_on_integers(n, h, w, cin, cout):
     assert torch.equal(dw.reshape(cout, cin * 9), ref), 'wgrad'
 
 
+@pytest.mark.parametrize('dt16', H16)
 @pytest.mark.parametrize('n,h,w,cin', [(1, 320, 479, 128), (2, 40, 59, 1024)])
-def test_convT_fwd_dgrad_wgrad_exact_on_integers(n, h, w, cin):
+def test_convT_fwd_dgrad_wgrad_exact_on_integers(n, h, w, cin, dt16):
     from unetk import ops
     cout = cin // 2
     hs, ws = 2 * h, 2 * w + 1                           # the reference's odd widths: one F.pad column on the right
     x = _ints((n, h, w, cin), 5).cuda()
     wt = _ints((cin, cout, 2, 2), 6, min(1.0, 64.0 / cin)).cuda()
     bias = _ints((cout,), 7).cuda()
-    cat = torch.full((n, hs, ws, cin), 3.0, dtype=torch.bfloat16, device='cuda')
-    ops.convT2x2_fwd(x.bfloat16(), ops.pack_weight(2, wt, cout, cin, torch.bfloat16), bias, cat, cout, cout, 0, 0)
+    cat = torch.full((n, hs, ws, cin), 3.0, dtype=dt16, device='cuda')
+    ops.convT2x2_fwd(x.to(dt16), ops.pack_weight(2, wt, cout, cin, dt16), bias, cat, cout, cout, 0, 0)
     ref = torch.empty((n, 2 * h, 2 * w, cout), device='cuda')          # independent evaluation: four GEMMs
     for a in (0, 1):
         for b in (0, 1):
@@ -102,7 +106,7 @@ def test_convT_fwd_dgrad_wgrad_exact_on_integers(n, h, w, cin):
 
     dcat = _ints((n, hs, ws, cin), 8).cuda()
     wd = _ints((cin, cout, 2, 2), 9, min(1.0, 16.0 / cout)).cuda()
-    dx = ops.convT2x2_dgrad(dcat.bfloat16(), cout, ops.pack_weight(3, wd, cout, cin, torch.bfloat16), cin, cout, h, w,
+    dx = ops.convT2x2_dgrad(dcat.to(dt16), cout, ops.pack_weight(3, wd, cout, cin, dt16), cin, cout, h, w,
                             0, 0)
     dup = dcat[:, :, :2 * w, cout:].permute(0, 3, 1, 2).contiguous()
     ref = sum(torch.einsum('nkij,ck->nijc', dup[:, :, a::2, b::2], wd[:, :, a, b]) for a in (0, 1) for b in (0, 1))
@@ -110,7 +114,7 @@ def test_convT_fwd_dgrad_wgrad_exact_on_integers(n, h, w, cin):
 
     dw = torch.empty_like(wt)
     db = torch.empty(cout, device='cuda')
-    ops.convT2x2_wgrad(x.bfloat16(), dcat.bfloat16(), cout, dw, db, 0, 0)
+    ops.convT2x2_wgrad(x.to(dt16), dcat.to(dt16), cout, dw, db, 0, 0)
     # dw[ci,co,a,b] = sum_{n,i,j} x[n,i,j,ci] * dup[n,co,2i+a,2j+b]
     ref = torch.stack([torch.stack([torch.einsum('nijc,nkij->ck', x, dup[:, :, a::2, b::2]) for b in (0, 1)], -1)
                        for a in (0, 1)], -2)
