@@ -90,6 +90,17 @@ class _UNetImpl:
             if ready is not None:
                 ready([p for p in params if p is not None], grads)
 
+        # a layer's weight gradient is queued behind the NEXT layer's BatchNorm-backward reduction (blocks.conv_bn_relu_bwd)
+        blocks.DEFER_WGRAD = blocks.DEFER_WGRAD_ENABLED
+        try:
+            out = self._bwd_body(saved, dlogits, grads, needs, net, ups, enc, done)
+            ops.run_deferred()               # the last layer's
+            return out
+        finally:
+            blocks.DEFER_WGRAD = False
+            ops.drop_deferred()              # (only non-empty after an exception)
+
+    def _bwd_body(self, saved, dlogits, grads, needs, net, ups, enc, done):
         # OutConv's input gradient is formed inside the BatchNorm backward of up4's last layer where it can be
         d, dhead = blocks.head_bwd(net.outc.conv, saved['head'], dlogits, grads, True, fuse_dx=True)
         if dhead is None:

@@ -192,6 +192,13 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
     return act, (x, y, st)
 
 
+# Set by the whole-net backward (unet/unet_model.py) while it runs: conv_bn_relu_bwd launches dgrad first and postpones the
+# layer's wgrad until the next layer's BatchNorm-backward reduction is queued, so that MFMA-bound and HBM-bound kernels
+# alternate (dgrad, reduce, wgrad, apply, dgrad ...) instead of running in pairs: +0.6 % images/sec in a same-box A/B
+# (UNETK_DEFER_WGRAD=0 restores wgrad-before-dgrad).  Stand-alone block Functions keep the plain order.
+DEFER_WGRAD = False
+DEFER_WGRAD_ENABLED = os.environ.get('UNETK_DEFER_WGRAD', '1') != '0'
+
 # fold the first layer's BN-backward reduction into the second layer's dgrad epilogue (UNETK_FUSE_BN_REDUCE=0: A/B runs)
 FUSE_BN_REDUCE = os.environ.get('UNETK_FUSE_BN_REDUCE', '1') != '0'
 
@@ -221,9 +228,19 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
         if need_dx:
             return ops.conv3x3_first_dgrad(dy, _f32c(conv.weight), c_in)
         return None
-    ops.conv3x3_wgrad(x, dy, dw)
-    if done is not None:
-        done(conv_bn_params(conv, bn))       # before the dgrad launch: the collective overlaps it
+    def wgrad():
+        ops.conv3x3_wgrad(x, dy, dw)
+        if done is not None:
+            done(conv_bn_params(conv, bn))
+    if DEFER_WGRAD and need_dx:
+        # whole-net backward: dgrad first, and the weight gradient behind the NEXT layer's BatchNorm-backward reduction
+        # (ops.bn_relu_bwd runs the postponed launch between its two passes) -- MFMA-bound and HBM-bound kernels then
+        # alternate instead of running in pairs
+        dx = ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums,
+                               bn_prev=bn_prev)
+        ops.defer(wgrad)
+        return dx
+    wgrad()                                  # before the dgrad launch: the collective overlaps it
     if not need_dx:
         return None
     return ops.conv3x3_dgrad(dy, packed_weight(conv, 1, dy.dtype, c_out, c_in), c_in, out=dx_out, sums=dx_sums,
@@ -318,6 +335,7 @@ def up_into_cat(up_mod, x_low, cat, c_skip, dtype):
 def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None, done=None):
     """dcat_sums: per-channel sums of dcat from the dgrad that wrote it (ConvTranspose2d bias gradient for free)."""
     x_low, h, w, c_low, pad_t, pad_l = saved
+    ops.run_deferred()                       # parameter groups complete in layout order (unetk.ddp)
     if isinstance(up_mod, torch.nn.ConvTranspose2d):
         c_out = up_mod.out_channels
         ops.convT2x2_wgrad(x_low, dcat, c_skip, _grad_buf(grads, up_mod.weight), _grad_buf(grads, up_mod.bias), pad_t, pad_l,

@@ -484,6 +484,24 @@ def _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen):
     coef[0].copy_(state.scale)
 
 
+# Launches a caller postponed so that they sit BETWEEN HBM-bound passes (unetk.blocks: a layer's weight gradient is
+# queued behind the next layer's BatchNorm-backward reduction instead of back to back with its own dgrad).
+_DEFERRED = []
+
+
+def defer(launch):
+    _DEFERRED.append(launch)
+
+
+def run_deferred():
+    while _DEFERRED:
+        _DEFERRED.pop(0)()
+
+
+def drop_deferred():
+    del _DEFERRED[:]
+
+
 def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhead=None, sums=None, frozen=False):
     """Returns dL/dy (gradient w.r.t. the conv output); writes dgamma/dbeta (fp32 [C]).
     frozen: the forward used the running statistics (see _bn_bwd_finalize).
@@ -525,6 +543,8 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
         check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
                                              state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
                                              sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
+    if not have_sums:
+        run_deferred()                       # behind the reduction pass ...
     _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen)
     if dpool is not None:
         check(fn['unetk_bn_relu_bwd_apply_pool'](dout.data_ptr(), lddo, dpool.data_ptr(), lddp, y.data_ptr(), ldy,
@@ -535,6 +555,8 @@ def bn_relu_bwd(dout, y, state, gamma, dgamma, dbeta, out=None, dpool=None, dhea
         check(fn['unetk_bn_relu_bwd_apply'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
                                             state.shift.data_ptr(), state.mean.data_ptr(), coef.data_ptr(),
                                             out.data_ptr(), ldo, npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_apply')
+    if have_sums:
+        run_deferred()                       # ... or, when the producer's dgrad already reduced, behind the apply pass
     return out
 
 

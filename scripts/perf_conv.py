@@ -11,7 +11,7 @@ layers = [(640, 959, 64, 64), (640, 959, 128, 64), (320, 479, 64, 128), (320, 47
           (640, 959, 64, 128)]          # the shape of up4's first conv as a dgrad (GEMM-K 64, GEMM-N 128)
 if os.environ.get('ONLY'):
     layers = [layers[int(i)] for i in os.environ['ONLY'].split(',')]
-dt = torch.bfloat16 if os.environ.get('DT', 'bf16') == 'bf16' else torch.float32
+dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[os.environ.get('DT', 'bf16')]
 for (h, w, cin, cout) in layers:
     x = (torch.rand((N, h, w, cin), device='cuda') - 0.5).to(dt)
     wt = (torch.rand((cout, cin, 3, 3), device='cuda') - 0.5) * 0.05
