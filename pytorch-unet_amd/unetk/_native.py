@@ -101,6 +101,7 @@ class KernelTimer:
     def __init__(self):
         self.records = []      # (name, start_event, end_event, flops, device kernel, conv bytes, call arguments)
         self._saved = None
+        self._ms = None
 
     @staticmethod
     def _flops(name, a):
@@ -213,24 +214,42 @@ class KernelTimer:
             return 'pool_upsample', 5.0 * n * h * w * c * es(a[12])
         return None, 0.0
 
+    def durations(self):
+        """Milliseconds between the two events of every record -- call after torch.cuda.synchronize()."""
+        if self._ms is None:
+            self._ms = [r[1].elapsed_time(r[2]) for r in self.records]
+        return self._ms
+
+    def take_median(self, others):
+        """Replace, launch by launch, this pass's duration by the median over this and the other passes (same launch
+        sequence required; returns False and changes nothing otherwise).  An event pair also spans any time the GPU
+        waits for the HOST to submit the launch between them: one hiccup of the launching thread in one pass must not
+        be booked as kernel time, and a median -- unlike a minimum -- does not bias the average downwards."""
+        names = [r[0] for r in self.records]
+        if any([r[0] for r in o.records] != names for o in others):
+            return False
+        cols = [self.durations()] + [o.durations() for o in others]
+        self._ms = [sorted(v)[len(v) // 2] for v in zip(*cols)]
+        return True
+
     def by_hbm_family(self):
         """{family: (launches, total_ms, total_algorithmic_bytes)} over the HBM-bound launches."""
         out = {}
-        for rec in self.records:
+        for rec, dur in zip(self.records, self.durations()):
             fam, nbytes = self._hbm(rec[0], rec[6])
             if fam is not None:
                 n, ms, b = out.get(fam, (0, 0.0, 0.0))
-                out[fam] = (n + 1, ms + rec[1].elapsed_time(rec[2]), b + nbytes)
+                out[fam] = (n + 1, ms + dur, b + nbytes)
         return out
 
     def by_device_kernel(self):
         """{device kernel: (launches, total_ms, total_flops, total_algorithmic_bytes)} over the conv3x3 fprop/dgrad
         launches."""
         out = {}
-        for name, s, e, fl, kern, nbytes, _ in self.records:
+        for (name, s, e, fl, kern, nbytes, _), dur in zip(self.records, self.durations()):
             if kern is not None:
                 n, ms, f, b = out.get(kern, (0, 0.0, 0.0, 0.0))
-                out[kern] = (n + 1, ms + s.elapsed_time(e), f + fl, b + nbytes)
+                out[kern] = (n + 1, ms + dur, f + fl, b + nbytes)
         return out
 
     def __enter__(self):
@@ -257,7 +276,7 @@ class KernelTimer:
     def summary(self):
         """{name: (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for name, s, e, fl, _, _, _ in self.records:
+        for (name, s, e, fl, _, _, _), dur in zip(self.records, self.durations()):
             n, ms, f = out.get(name, (0, 0.0, 0.0))
-            out[name] = (n + 1, ms + s.elapsed_time(e), f + fl)
+            out[name] = (n + 1, ms + dur, f + fl)
         return out
