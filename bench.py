@@ -385,7 +385,8 @@ def main(argv=None):
                 roofline_hbm['batchnorm_family'] = leg(*[sum(v[i] for v in bn) for i in range(3)])
             roofline_hbm['all'] = leg(*[sum(v[i] for v in fams.values()) for i in range(3)])
             roofline_hbm['note'] = ('algorithmic bytes = every tensor a pass must read or write, once, from the call '
-                                    'arguments; time = HIP events around each launch on its stream (one step)')
+                                    'arguments; time = HIP events around each launch on its stream (one step; per-launch median of the '
+                                    'timing passes)')
         total_ms = sum(v[1] for v in table.values())
         sys.stderr.write('kernel-time table of one step (HIP events, serialised by the event brackets):\n')
         for name, (n, m, f) in sorted(table.items(), key=lambda kv: -kv[1][1]):
