@@ -259,6 +259,7 @@ struct FirstWgradParams {
 
 // rows i = k = tap*4 + ci (36 used of 64), cols = 64 output channels, GEMM-K = pixels.
 // Each wave takes 2 of the 8 tile rows and keeps a full 64x64 accumulator; waves are summed through LDS at the end.
+// (H: bf16 or f16; the name is kept from the bf16-only generation, profiles/ refers to it)
 template <typename H>
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgradParams P) {
   typedef typename H16<H>::x8 h8;

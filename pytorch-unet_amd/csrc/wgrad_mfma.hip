@@ -49,7 +49,8 @@ __device__ __forceinline__ frag5_t tr_read8(const char* lds0, const char* lds1) 
 __device__ __forceinline__ int swz(int p) { return ((p >> 1) & 1) << 2; }
 
 
-// H = the 16-bit element type of the kernel (bf16 or f16): the kernels move 16-bit words (u16) and differ only here
+// H = the 16-bit element type of the kernel (bf16 or f16): the kernels move 16-bit words (u16) and differ only here.
+// (The `_bf16_` in the kernel names dates from the bf16-only generation and is kept: profiles/ refers to them.)
 #define WG_MFMA(a, b, c) \
   H16<H>::mfma32(__builtin_bit_cast(typename H16<H>::x8, a), __builtin_bit_cast(typename H16<H>::x8, b), c)
 
