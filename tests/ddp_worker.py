@@ -1,6 +1,6 @@
 """One rank of tests/test_gpu_ddp_two_ranks.py (started as a child process; not collected by pytest).
 
-    python tests/ddp_worker.py <rank> <world> <port> <out dir>
+    python tests/ddp_worker.py <rank> <world> <port> <out dir> [bf16]
 
 Runs ONE training step (Trainer.step's sequence) of the real whole-net backward on this rank's own images -- the
 gradient buckets go out over `gloo` while the backward is still running (FlatGrads._launch stages each bucket through
@@ -36,14 +36,14 @@ def rank_batch(rank):
     return img, mask
 
 
-def run(rank, world, port, out):
+def run(rank, world, port, out, amp=False):
     from unet import UNet
     from unetk.trainer import Trainer
     print(f'rank {rank}/{world}: imports done', flush=True)
     if world > 1:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', world_size=world, rank=rank)
     net = closed_form(UNet(3, 2, False)).cuda().to(memory_format=torch.channels_last).train()
-    tr = Trainer(net, amp=False, learning_rate=1e-3, gradient_clipping=1.0, bucket_bytes=4 << 20)
+    tr = Trainer(net, amp=amp, learning_rate=1e-3, gradient_clipping=1.0, bucket_bytes=4 << 20)
     assert tr.sync.world == world and tr.sync.active == (world > 1)
     launches = [0]
     orig = tr.sync._launch
@@ -58,7 +58,8 @@ def run(rank, world, port, out):
     # Trainer.step's body (unetk/trainer.py), with a copy of the flat buffer taken between the all-reduce wait and the
     # optimizer (whose fused kernel scales the gradients by the clip coefficient in place)
     from unetk.loss import segmentation_loss
-    loss = segmentation_loss(net(img), mask)
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+        loss = segmentation_loss(net(img), mask)
     tr.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     tr.sync.finish()
@@ -78,4 +79,4 @@ def run(rank, world, port, out):
 if __name__ == '__main__':
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=True)          # a hung collective ends the rank with its stacks in the log
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], amp=len(sys.argv) > 5 and sys.argv[5] == 'bf16')

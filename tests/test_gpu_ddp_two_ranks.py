@@ -27,11 +27,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _spawn(rank, world, port, out):
+def _spawn(rank, world, port, out, amp=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
     log = open(os.path.join(str(out), f'rank{rank}.log'), 'w')
-    return subprocess.Popen([sys.executable, WORKER, str(rank), str(world), str(port), str(out)], env=env,
-                            stdout=log, stderr=subprocess.STDOUT), log
+    return subprocess.Popen([sys.executable, WORKER, str(rank), str(world), str(port), str(out)] + (['bf16'] if amp else []),
+                            env=env, stdout=log, stderr=subprocess.STDOUT), log
 
 
 def _wait(procs, out):
@@ -48,30 +48,36 @@ def _wait(procs, out):
         assert p.returncode == 0, f'{log.name}:\n{text[-3000:]}'
 
 
-def test_two_rank_gradients_are_the_average_of_the_single_rank_gradients(tmp_path):
+@pytest.mark.parametrize('amp', [False, True])
+def test_two_rank_gradients_are_the_average_of_the_single_rank_gradients(tmp_path, amp):
+    """amp: the same under bf16 autocast.  The averaging itself is fp32 either way; what differs between the pair's run
+    and the single-rank references is the order of the BatchNorm fp64 atomics, whose last-bit differences bf16 storage
+    turns into ~1e-3 of gradient noise -- the tolerance on the average is wider there, bit-identity across the two
+    ranks is not."""
+    tol = 2e-2 if amp else 1e-4
     two, one = tmp_path / 'two', tmp_path / 'one'
     two.mkdir()
     one.mkdir()
     port = _free_port()
-    _wait([_spawn(r, 2, port, two) for r in (0, 1)], two)        # the pair, concurrently
+    _wait([_spawn(r, 2, port, two, amp) for r in (0, 1)], two)   # the pair, concurrently
     for r in (0, 1):                                             # each rank's images alone (world size 1)
-        _wait([_spawn(r, 1, 0, one)], one)
+        _wait([_spawn(r, 1, 0, one, amp)], one)
     d2 = [np.load(two / f'rank{r}.npz') for r in (0, 1)]
     d1 = [np.load(one / f'rank{r}.npz') for r in (0, 1)]
     assert int(d2[0]['buckets']) >= 5 and int(d1[0]['buckets']) == 0      # 124 MB of gradients in 4 MB buckets
     g0, g1 = d1[0]['flat'].astype(np.float64), d1[1]['flat'].astype(np.float64)
     assert np.linalg.norm(g0 - g1) > 0.05 * np.linalg.norm(g0)           # the ranks really saw different data
     for r in (0, 1):
-        assert abs(float(d2[r]['loss']) - float(d1[r]['loss'])) <= 1e-5 * abs(float(d1[r]['loss']))   # forward is local
+        assert abs(float(d2[r]['loss']) - float(d1[r]['loss'])) <= (1e-3 if amp else 1e-5) * abs(float(d1[r]['loss']))   # forward is local
     mean = 0.5 * (g0 + g1)
     scale = np.linalg.norm(mean)
     assert scale > 0
     for r in (0, 1):
-        assert np.linalg.norm(d2[r]['flat'] - mean) <= 1e-4 * scale, (r, np.linalg.norm(d2[r]['flat'] - mean) / scale,
+        assert np.linalg.norm(d2[r]['flat'] - mean) <= tol * scale, (r, np.linalg.norm(d2[r]['flat'] - mean) / scale,
                                                                       np.linalg.norm(d2[r]['flat'] - g0) / scale)
     assert np.array_equal(d2[0]['flat'], d2[1]['flat'])                   # bit-identical on both ranks
     assert float(d2[0]['total_norm']) == float(d2[1]['total_norm'])
-    assert abs(float(d2[0]['total_norm']) - scale) <= 1e-4 * scale        # the clip saw the AVERAGED gradient
+    assert abs(float(d2[0]['total_norm']) - scale) <= tol * scale         # the clip saw the AVERAGED gradient
     for k in ('outc', 'inc'):
         assert np.array_equal(d2[0][k], d2[1][k])                         # same step on both ranks
         assert not np.array_equal(d2[0][k], d1[0][k])                     # ... and not rank 0's own
