@@ -17,6 +17,10 @@
 // fixed order (bitwise reproducible, no float atomics) and writes PyTorch's parameter layout.
 #include "common.h"
 
+#ifndef UNETK_WGRAD_REDUCE_V4
+#define UNETK_WGRAD_REDUCE_V4 1      /* split-K reduction with 16-byte slab loads (0: A/B builds) */
+#endif
+
 namespace {
 
 typedef unsigned short u16;   // a 16-bit element as the data movement sees it (bf16 or fp16)
@@ -1097,6 +1101,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int col_tiles = cols / 32;
   const int c0 = (blockIdx.x % col_tiles) * 32, r0 = (blockIdx.x / col_tiles) * 8;
   const long total = (long)taps * rows * cols;
+#if UNETK_WGRAD_REDUCE_V4
+  // 16-byte slab loads: a thread owns four adjacent columns of one row, thread groups of 64 take the taps in turn
+  // (four independent load streams per workgroup instead of one 4-byte load per lane and split)
+  const int c4 = (threadIdx.x & 7) * 4, rl = (threadIdx.x >> 3) & 7, tg = threadIdx.x >> 6;
+  for (int t = tg; t < taps; t += 4) {
+    const long idx = ((long)t * rows + r0 + rl) * cols + c0 + c4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slab + (size_t)k * total + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(t * 8 + rl) * 33 + c4 + e] = s[e];
+  }
+#else
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   for (int t = 0; t < taps; ++t) {
     const long idx = ((long)t * rows + r0 + rl) * cols + c0 + cl;
@@ -1104,6 +1120,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + idx];
     tile[(t * 8 + rl) * 33 + cl] = s;
   }
+#endif
   __syncthreads();
   const int per_col = 8 * taps;
   for (int e = threadIdx.x; e < 32 * per_col; e += 256) {
