@@ -182,7 +182,9 @@ int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const f
 /* The same apply for the LAST block's last layer, which feeds OutConv (unet_model.py:35, unet_parts.py:74): besides
  * out = relu(y*scale+shift) it emits logits[p][k] = sum_c out[p][c] * w[k][c] + bias[k] (w the fp32 parameter
  * [n_classes][c]; the arithmetic of unetk_conv1x1_fwd on the rounded activation) -- no pass over the activation.
- * UNETK_ERR_SHAPE when n_classes > 4 or c/(16/es) is not a power of two <= 64: use bn_relu_apply + conv1x1_fwd. */
+ * UNETK_ERR_SHAPE when n_classes > 4 or c/(16/es) is not a power of two <= 64: use bn_relu_apply + conv1x1_fwd.
+ * out may be NULL: the activation is then not stored (nothing reads it when the backward pass forms OutConv's
+ * gradients from y -- unetk_bn_relu_bwd_reduce_head / _apply_head -- or when there is no backward pass). */
 int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
                              const float* w, const float* bias, int n_classes, void* logits, int ldl, int64_t npix,
                              int c, int dtype, void* stream);

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __rest
       float a[E];
 #pragma unroll
       for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaf(raw_elem<T>(raw, i), sc[i], sh[i]), 0.f);
-      if (live) Vec<T>::store(out + p * ldo + c0, a);
+      if (live && out != nullptr) Vec<T>::store(out + p * ldo + c0, a);
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) {
         float d = 0.f;
@@ -1223,9 +1223,10 @@ int unetk_bn_relu_bwd_apply(const void* dout, int lddo, const void* y, int ldy, 
 int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const float* shift, void* out, int ldo,
                              const float* w, const float* bias, int n_classes, void* logits, int ldl, int64_t npix,
                              int c, int dtype, void* stream) {
-  if (!y || !scale || !shift || !out || !w || !bias || !logits || npix <= 0) return UNETK_ERR_ARG;
+  if (!y || !scale || !shift || !w || !bias || !logits || npix <= 0) return UNETK_ERR_ARG;
   if (int e = check_act(y, ldy, c, dtype)) return e;
-  if (int e = check_act(out, ldo, c, dtype)) return e;
+  if (out != nullptr)                       // NULL: only the logits are wanted (see unetk.h)
+    if (int e = check_act(out, ldo, c, dtype)) return e;
   const int E = unetk_epp(dtype);
   const int ppp = c / E;
   // a pixel's lanes must share a wave for the shuffle sum: ppp a power of two <= 64

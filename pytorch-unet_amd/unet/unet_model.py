@@ -60,7 +60,7 @@ class _UNetImpl:
             cat, c_skip = skips[3 - k]
             saved['up'].append(blocks.up_into_cat(up.up, cur, cat, c_skip, dt))
             # the last block's BatchNorm+ReLU kernel also emits OutConv's logits where it can
-            head = {'conv': net.outc.conv} if k == 3 else None
+            head = {'conv': net.outc.conv, 'logits_only': True} if k == 3 else None
             cur, s = blocks.double_conv_fwd(up.conv, cat, dt, head=head)
             saved['dec'].append(s)
             saved['cats'].append(c_skip)

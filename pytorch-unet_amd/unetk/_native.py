@@ -167,7 +167,7 @@ class KernelTimer:
             n, h, w, c = a[8:12]
             return 'bn_apply', (2.0 * n * h * w + n * (h // 2) * (w // 2)) * c * es(a[12])
         if name == 'unetk_bn_relu_apply_head':                # + the logits
-            return 'bn_apply', (2.0 * a[12] + a[8]) * a[11] * es(a[13])
+            return 'bn_apply', ((2.0 if a[4] else 1.0) * a[12] + a[8]) * a[11] * es(a[13])   # out may be NULL
         if name == 'unetk_bn_relu_bwd_reduce':                # read dout, z
             return 'bn_bwd_reduce', 2.0 * a[9] * a[10] * es(a[11])
         if name == 'unetk_bn_relu_bwd_reduce_pool':           # read dskip, z, dpool

@@ -185,8 +185,13 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
             and head['conv'].kernel_size == (1, 1):
         hc = head['conv']
         wh = _f32c(hc.weight)
-        act, logits = ops.bn_relu_apply_head(y, st, wh.reshape(hc.out_channels, c_out), _f32c(hc.bias), out=out)
-        head['logits'], head['saved'] = logits, (act, wh)
+        # head['logits_only'] (the whole-net forward): the activation itself has no reader -- OutConv's gradients are
+        # re-formed from y in the BatchNorm backward (head_bwd_fusable), or there is no backward -- so it is not stored
+        skip = bool(head.get('logits_only')) and out is None and ops.head_bwd_fusable(c_out, hc.out_channels, dtype) \
+            and not HEAD_STORE_ACT
+        act, logits = ops.bn_relu_apply_head(y, st, wh.reshape(hc.out_channels, c_out), _f32c(hc.bias), out=out,
+                                             store_act=not skip)
+        head['logits'], head['saved'] = logits, (act, wh, dtype)
         return act, (x, y, st)
     act = ops.bn_relu_apply(y, st, out=out, pool_out=pool_out)
     return act, (x, y, st)
@@ -198,6 +203,9 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
 # (UNETK_DEFER_WGRAD=0 restores wgrad-before-dgrad).  Stand-alone block Functions keep the plain order.
 DEFER_WGRAD = False
 DEFER_WGRAD_ENABLED = os.environ.get('UNETK_DEFER_WGRAD', '1') != '0'
+
+# UNETK_HEAD_STORE_ACT=1 (A/B runs): the whole-net forward stores the last activation although nothing reads it
+HEAD_STORE_ACT = os.environ.get('UNETK_HEAD_STORE_ACT', '0') != '0'
 
 # fold the first layer's BN-backward reduction into the second layer's dgrad epilogue (UNETK_FUSE_BN_REDUCE=0: A/B runs)
 FUSE_BN_REDUCE = os.environ.get('UNETK_FUSE_BN_REDUCE', '1') != '0'
@@ -380,11 +388,14 @@ def head_bwd(conv, saved, dl, grads, need_dx=True, fuse_dx=False):
     """Returns (input gradient, None), or with fuse_dx -- when the consumer's BatchNorm backward can form the input
     gradient and OutConv's own weight/bias gradient on the fly (ops.head_bwd_fusable) -- (None, dhead): nothing is
     launched here and the caller passes `dhead` on to double_conv_bwd of the block that fed OutConv."""
-    x, w = saved
-    if dl.dtype != x.dtype:
-        dl = dl.to(x.dtype)
+    x, w = saved[0], saved[1]
+    dtype = saved[2] if len(saved) > 2 else x.dtype      # (x is None when the fused forward stored no activation)
+    if dl.dtype != dtype:
+        dl = dl.to(dtype)
     n_classes, c = conv.out_channels, conv.in_channels
     dw, db = _grad_buf(grads, conv.weight), _grad_buf(grads, conv.bias)
-    if need_dx and fuse_dx and ops.head_bwd_fusable(c, n_classes, x.dtype):
+    if need_dx and fuse_dx and ops.head_bwd_fusable(c, n_classes, dtype):
         return None, (dl, w.reshape(n_classes, c), dw, db)
+    if x is None:
+        raise RuntimeError('OutConv backward: the forward kept no activation and the fused backward does not apply')
     return ops.conv1x1_bwd(x, dl, w, dw, db, need_dx), None

@@ -382,19 +382,25 @@ def head_fwd_fusable(c, n_classes, dtype):
     return n_classes <= 4 and c % e == 0 and 0 < ppp <= 64 and (ppp & (ppp - 1)) == 0
 
 
-def bn_relu_apply_head(y, state, w_head, bias, out=None):
-    """relu(bn(y)) AND OutConv's logits [N,H,W,n_classes] of it (w_head fp32 [n_classes, C], bias fp32)."""
+def bn_relu_apply_head(y, state, w_head, bias, out=None, store_act=True):
+    """relu(bn(y)) AND OutConv's logits [N,H,W,n_classes] of it (w_head fp32 [n_classes, C], bias fp32).
+    store_act=False: only the logits (returns (None, logits)) -- the activation is one full-resolution tensor that
+    nothing reads when the backward pass re-forms it from y (head_bwd_fusable) or does not exist."""
     n, h, w, c, ldy = nhwc_meta(y, 'bn input')
     ncls = w_head.shape[0]
     if w_head.dtype != torch.float32 or bias.dtype != torch.float32 or w_head.numel() != ncls * c \
             or not w_head.is_contiguous():
         raise RuntimeError('bn_relu_apply_head: OutConv weight must be contiguous fp32 [n_classes, C]')
-    if out is None:
-        out = new_nhwc(n, h, w, c, y.dtype, y.device)
-    _, _, _, _, ldo = nhwc_meta(out, 'bn output')
+    if not store_act:
+        out, out_ptr, ldo = None, None, c
+    else:
+        if out is None:
+            out = new_nhwc(n, h, w, c, y.dtype, y.device)
+        _, _, _, _, ldo = nhwc_meta(out, 'bn output')
+        out_ptr = out.data_ptr()
     logits = new_nhwc(n, h, w, ncls, y.dtype, y.device)
     check(fn['unetk_bn_relu_apply_head'](y.data_ptr(), ldy, state.scale.data_ptr(), state.shift.data_ptr(),
-                                         out.data_ptr(), ldo, w_head.data_ptr(), bias.data_ptr(), ncls,
+                                         out_ptr, ldo, w_head.data_ptr(), bias.data_ptr(), ncls,
                                          logits.data_ptr(), ncls, n * h * w, c, dtype_code(y.dtype), stream_ptr()),
           'unetk_bn_relu_apply_head')
     return out, logits

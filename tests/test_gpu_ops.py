@@ -591,6 +591,9 @@ def test_bn_relu_apply_head_equals_apply_then_conv1x1(dtype, ncls, npix_shape):
     assert torch.equal(act, ref_act)
     assert torch.equal(cat[..., c:].float(), torch.full((n, h, w, 64), 5.0, device='cuda'))
     assert logits.shape == ref_logits.shape and torch.equal(logits, ref_logits)
+    # logits only (what the whole-net forward asks for: nothing reads the activation): the same logits, nothing stored
+    none, logits2 = ops.bn_relu_apply_head(y, st, wh, bias, store_act=False)
+    assert none is None and torch.equal(logits2, ref_logits)
 
 
 def test_scratch_buffers_are_per_stream():
