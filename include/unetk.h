@@ -110,6 +110,19 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
                               int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
                               void* stream);
 
+/* The same weight gradient together with the layer's BatchNorm2d+ReLU backward (autograd of unet_parts.py:16-18 at the
+ * network's first layer, whose input -- the image of train.py:97 -- needs no gradient): the gradient w.r.t. the
+ * convolution's output has no reader but this kernel, so it is formed on the fly and never stored,
+ *   dy = coef[0][c] * (scale[c]*z + shift[c] > 0 ? dout : 0) - coef[1][c] - coef[2][c] * (z - mean[c]),
+ * the expression and rounding of unetk_bn_relu_bwd_apply: dw equals unetk_bn_relu_bwd_apply followed by
+ * unetk_conv3x3_first_wgrad bit for bit.  dout: gradient w.r.t. the layer's activation (pitch lddo); z: the
+ * convolution's saved output (pitch ldz); coef: [3][c_out] from unetk_bn_relu_bwd_finalize.  bf16 / fp16 only
+ * (UNETK_ERR_DTYPE for fp32: run the two entry points). */
+int unetk_conv3x3_first_wgrad_bn(const float* x, int ldx, const void* dout, int lddo, const void* z, int ldz,
+                                 const float* scale, const float* shift, const float* mean, const float* coef,
+                                 float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int c_in,
+                                 int c_out, int dtype, void* stream);
+
 /* Gradient w.r.t. the network INPUT of that layer (autograd of unet_parts.py:16 when the image requires a gradient --
  * the reference's train loop never does, saliency / adversarial uses do): dx fp32 [n][h][wd][c_in] (pitch lddx),
  * dx[q][ci] = sum_{tap,co} dy[q - (tap - 1)][co] * w[co][ci][tap]; w is the UNPACKED parameter; c_out <= 512. */

@@ -255,12 +255,23 @@ struct FirstWgradParams {
   float* slab;        // [nsplit][col_tiles][64 rows (k)][64 cols]
   int N, H, W, Cin, Cout, ldx, lddy;
   int tiles_x, tiles_y, ntiles, nsplit, col_tiles;
+  // BNF (unetk_conv3x3_first_wgrad_bn): `dy` is the gradient w.r.t. the layer's ACTIVATION (pitch lddy) and the gradient
+  // w.r.t. the convolution's output is formed on the fly from it and the layer's pre-BatchNorm tensor z (pitch ldz),
+  // exactly as unetk_bn_relu_bwd_apply would have stored it
+  const void* z;
+  int ldz;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_coef;     // coef: [3][Cout]
 };
 
 // rows i = k = tap*4 + ci (36 used of 64), cols = 64 output channels, GEMM-K = pixels.
 // Each wave takes 2 of the 8 tile rows and keeps a full 64x64 accumulator; waves are summed through LDS at the end.
 // (H: bf16 or f16; the name is kept from the bf16-only generation, profiles/ refers to it)
-template <typename H>
+// BNF: the first layer's input needs no gradient, so the BatchNorm+ReLU backward's apply pass would write the conv-output
+// gradient (one full-resolution tensor) only for this kernel to read it back once: here a thread loads its 16-byte
+// pieces of the activation gradient and of z instead, applies  dy = c0 * dz - c1 - c2 * (z - mean)  (the expression of
+// bn_relu_bwd_apply_kernel, rounded to H the same way) and writes the piece into the LDS tile the LDS-DMA would have
+// filled -- a thread keeps ONE channel piece, its 48 coefficients live in registers.
+template <typename H, bool BNF = false>
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgradParams P) {
   typedef typename H16<H>::x8 h8;
   typedef typename H16<H>::x4 h4;
@@ -310,6 +321,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
 
   const char* zero = reinterpret_cast<const char*>(g_zero_page_first);
   const int lp = lane >> 3, ls = lane & 7;
+  float bsc[8], bsh[8], bmu[8], bk0[8], bk1[8], bk2[8];
+  if constexpr (BNF) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = ct * 64 + ls * 8 + i;
+      bsc[i] = P.bn_scale[c]; bsh[i] = P.bn_shift[c]; bmu[i] = P.bn_mean[c];
+      bk0[i] = P.bn_coef[c]; bk1[i] = P.bn_coef[P.Cout + c]; bk2[i] = P.bn_coef[2 * P.Cout + c];
+    }
+  }
 
   for (int tile = t_begin; tile < t_end; ++tile) {
     int tt = tile;
@@ -318,17 +338,47 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
     const int img = tt / P.tiles_y;
     const int y0 = ty * 8, x0 = tx * 32;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // dy tile by LDS-DMA
     const H* dimg = reinterpret_cast<const H*>(P.dy) + (size_t)img * P.H * P.W * P.lddy + ct * 64;
+    if constexpr (BNF) {
+      // dy tile from the activation gradient and z: logical piece ls of pixel p goes to slot ls ^ swizzle(p)
+      const H* zimg = reinterpret_cast<const H*>(P.z) + (size_t)img * P.H * P.W * P.ldz + ct * 64;
+      typedef typename H16<H>::x8 h8;
+      h8 g8[8], z8[8];
+      bool in[8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int fi = f * 4 + wid;
-      const int p = fi * 8 + lp;
-      const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
-      const int c = ls ^ (((p >> 1) & 1) << 2);
-      const char* src = zero;
-      if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(dimg + (size_t)(yy * P.W + xx) * P.lddy + c * 8);
-      glds16(src, lds_dy + fi * 1024);
+      for (int f = 0; f < 8; ++f) {
+        const int p = (f * 4 + wid) * 8 + lp;
+        const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+        in[f] = yy < P.H && xx < P.W;
+        const size_t pix = in[f] ? (size_t)(yy * P.W + xx) : 0;
+        g8[f] = *reinterpret_cast<const h8*>(dimg + pix * P.lddy + ls * 8);
+        z8[f] = *reinterpret_cast<const h8*>(zimg + pix * P.ldz + ls * 8);
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int p = (f * 4 + wid) * 8 + lp;
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (float)z8[f][i], g = (float)g8[f][i];
+          const float dz = fmaf(v, bsc[i], bsh[i]) > 0.f ? g : 0.f;
+          const float r = bk0[i] * dz - bk1[i] - bk2[i] * (v - bmu[i]);
+          o[i] = in[f] ? (H)r : (H)0.f;
+        }
+        *reinterpret_cast<h8*>(lds_dy + p * 128 + ((ls ^ (((p >> 1) & 1) << 2)) << 4)) = o;
+      }
+    } else {
+      // dy tile by LDS-DMA
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int fi = f * 4 + wid;
+        const int p = fi * 8 + lp;
+        const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+        const int c = ls ^ (((p >> 1) & 1) << 2);
+        const char* src = zero;
+        if (yy < P.H && xx < P.W) src = reinterpret_cast<const char*>(dimg + (size_t)(yy * P.W + xx) * P.lddy + c * 8);
+        glds16(src, lds_dy + fi * 1024);
+      }
     }
     // image halo tile, fp32 -> bf16
     const float* ximg = P.x + (size_t)img * P.H * P.W * P.ldx;
@@ -379,18 +429,22 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_bf16_kernel(FirstWgra
   // ---- sum the 4 waves through LDS, write the block's partial [64][64]
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   float* red = reinterpret_cast<float*>(smem);   // [64][64] floats = 16 KB
-  for (int i = tid; i < 64 * 64; i += 256) red[i] = 0.f;
-  __syncthreads();
+  // one wave at a time, in wave order: the sum is the same bit pattern on every run
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wid == wv) {
 #pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
+      for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+        for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        atomicAdd(&red[row * 64 + jb * 32 + r], acc[ib][jb][i]);
-      }
-  __syncthreads();
+          for (int i = 0; i < 16; ++i) {
+            const int row = ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float* dst = &red[row * 64 + jb * 32 + r];
+            *dst = wv == 0 ? acc[ib][jb][i] : *dst + acc[ib][jb][i];
+          }
+    }
+    __syncthreads();
+  }
   float* out = P.slab + ((size_t)split * P.col_tiles + ct) * 4096;
   for (int i = tid; i < 4096; i += 256) out[i] = red[i];
 }
@@ -470,13 +524,18 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_f32_kernel(FirstWgrad
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   float* red = reinterpret_cast<float*>(smem);   // [64][32]
-  for (int i = tid; i < 64 * 32; i += 256) red[i] = 0.f;
-  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {                 // in wave order (see the 16-bit kernel)
+    if (wid == wv) {
 #pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
+      for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) atomicAdd(&red[(ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r], acc[ib][i]);
-  __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+          float* dst = &red[(ib * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + r];
+          *dst = wv == 0 ? acc[ib][i] : *dst + acc[ib][i];
+        }
+    }
+    __syncthreads();
+  }
   // slab layout shared with the bf16 kernel: [split][64-col tile][64 rows][64 cols]
   float* out = P.slab + ((size_t)split * (P.col_tiles / 2) + (ct >> 1)) * 4096 + (ct & 1) * 32;
   for (int i = tid; i < 64 * 32; i += 256) out[(i >> 5) * 64 + (i & 31)] = red[i];
@@ -618,9 +677,10 @@ int64_t unetk_conv3x3_first_wgrad_workspace_bytes(int n, int h, int w, int c_out
   return (int64_t)first_nsplit(ntiles, c_out / 64) * (c_out / 64) * 4096 * sizeof(float);
 }
 
-int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
-                              int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
-                              void* stream) {
+static int first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                       int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype, void* stream,
+                       const void* z, int ldz, const float* scale, const float* shift, const float* mean,
+                       const float* coef) {
   if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
   const int64_t need = unetk_conv3x3_first_wgrad_workspace_bytes(n, h, w, c_out);
   if (need < 0) return (int)need;
@@ -633,7 +693,16 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.ntiles = n * P.tiles_x * P.tiles_y;
   P.col_tiles = c_out / 64;
   P.nsplit = first_nsplit(P.ntiles, P.col_tiles);
-  if (unetk_is16(dtype)) {
+  if (z != nullptr) {
+    if (!unetk_is16(dtype)) return UNETK_ERR_DTYPE;          // callers run the apply pass + the plain kernel in fp32
+    if (!scale || !shift || !mean || !coef) return UNETK_ERR_ARG;
+    if (ldz < c_out) return UNETK_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z) & 15) || (ldz * 2) % 16) return UNETK_ERR_ALIGN;
+    P.z = z; P.ldz = ldz; P.bn_scale = scale; P.bn_shift = shift; P.bn_mean = mean; P.bn_coef = coef;
+    const size_t lds = 256 * 128 + 340 * 8;
+    UNETK_WITH_H(dtype, hipLaunchKernelGGL((conv_first_wgrad_bf16_kernel<H, true>), dim3(P.nsplit * P.col_tiles),
+                                           dim3(256), lds, (hipStream_t)stream, P));
+  } else if (unetk_is16(dtype)) {
     const size_t lds = 256 * 128 + 340 * 8;
     UNETK_WITH_H(dtype, hipLaunchKernelGGL(conv_first_wgrad_bf16_kernel<H>, dim3(P.nsplit * P.col_tiles), dim3(256), lds,
                                            (hipStream_t)stream, P));
@@ -649,6 +718,22 @@ int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy,
                      (const float*)workspace, dw, P.nsplit, P.col_tiles, c_in, c_out);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
+}
+
+int unetk_conv3x3_first_wgrad(const float* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                              int64_t workspace_bytes, int n, int h, int w, int c_in, int c_out, int dtype,
+                              void* stream) {
+  return first_wgrad(x, ldx, dy, lddy, dw, workspace, workspace_bytes, n, h, w, c_in, c_out, dtype, stream, nullptr, 0,
+                     nullptr, nullptr, nullptr, nullptr);
+}
+
+int unetk_conv3x3_first_wgrad_bn(const float* x, int ldx, const void* dout, int lddo, const void* z, int ldz,
+                                 const float* scale, const float* shift, const float* mean, const float* coef,
+                                 float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int c_in,
+                                 int c_out, int dtype, void* stream) {
+  if (!z) return UNETK_ERR_ARG;
+  return first_wgrad(x, ldx, dout, lddo, dw, workspace, workspace_bytes, n, h, w, c_in, c_out, dtype, stream, z, ldz,
+                     scale, shift, mean, coef);
 }
 
 int unetk_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int lddx, int n, int h, int wd,

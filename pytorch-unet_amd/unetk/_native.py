@@ -120,6 +120,8 @@ class KernelTimer:
             return 2.0 * a[6] * a[7] * a[8] * 9 * a[9] * a[10]
         if name == 'unetk_conv3x3_first_wgrad':
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
+        if name == 'unetk_conv3x3_first_wgrad_bn':
+            return 2.0 * a[13] * a[14] * a[15] * 9 * a[16] * a[17]
         if name == 'unetk_convT2x2_fwd':
             return 2.0 * a[7] * a[8] * a[9] * 4 * a[10] * a[11]
         if name == 'unetk_convT2x2_dgrad':
@@ -197,6 +199,9 @@ class KernelTimer:
         if name == 'unetk_conv3x3_first_wgrad':               # read the image and dy
             n, h, w, ci, co = a[7:12]
             return 'first_layer', 1.0 * n * h * w * (4 * ci + co * es(a[12]))
+        if name == 'unetk_conv3x3_first_wgrad_bn':            # read the image, dout and z
+            n, h, w, ci, co = a[13:18]
+            return 'first_layer', 1.0 * n * h * w * (4 * ci + 2 * co * es(a[18]))
         if name == 'unetk_seg_loss_fwd':                      # logits + int64 mask
             return 'loss', 1.0 * a[3] * (a[4] * es(a[8]) + 8)
         if name == 'unetk_seg_loss_bwd':                      # logits + mask, write dlogits

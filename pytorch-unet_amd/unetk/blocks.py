@@ -207,6 +207,9 @@ DEFER_WGRAD_ENABLED = os.environ.get('UNETK_DEFER_WGRAD', '1') != '0'
 # UNETK_HEAD_STORE_ACT=1 (A/B runs): the whole-net forward stores the last activation although nothing reads it
 HEAD_STORE_ACT = os.environ.get('UNETK_HEAD_STORE_ACT', '0') != '0'
 
+# UNETK_FUSE_FIRST_WGRAD=0 (A/B runs): the first layer's BatchNorm-backward apply pass and weight gradient stay two kernels
+FUSE_FIRST_WGRAD = os.environ.get('UNETK_FUSE_FIRST_WGRAD', '1') != '0'
+
 # fold the first layer's BN-backward reduction into the second layer's dgrad epilogue (UNETK_FUSE_BN_REDUCE=0: A/B runs)
 FUSE_BN_REDUCE = os.environ.get('UNETK_FUSE_BN_REDUCE', '1') != '0'
 
@@ -227,8 +230,16 @@ def conv_bn_relu_bwd(conv, bn, saved, dact, grads, need_dx, dx_out=None, dpool=N
     frozen = not _bn_uses_batch_stats(bn)       # eval-mode BatchNorm: running statistics are constants of the graph
     dgamma = _grad_buf(grads, bn.weight) if bn.weight is not None else None
     dbeta = _grad_buf(grads, bn.bias) if bn.bias is not None else None
-    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead, sums=bn_sums, frozen=frozen)
     dw = _grad_buf(grads, conv.weight)
+    if c_in <= 4 and not need_dx and FUSE_FIRST_WGRAD and dpool is None and dhead is None \
+            and ops.first_wgrad_bn_fusable(y.dtype):
+        # the training loop's first layer: nothing reads the conv-output gradient but the weight-gradient kernel, which
+        # forms it on the fly (one full-resolution tensor neither written nor read back)
+        ops.bn_relu_bwd_first_wgrad(dact, y, st, bn.weight, dgamma, dbeta, x, dw, sums=bn_sums, frozen=frozen)
+        if done is not None:
+            done(conv_bn_params(conv, bn))
+        return None
+    dy = ops.bn_relu_bwd(dact, y, st, bn.weight, dgamma, dbeta, dpool=dpool, dhead=dhead, sums=bn_sums, frozen=frozen)
     if c_in <= 4:
         ops.conv3x3_first_wgrad(x, dy, dw)
         if done is not None:

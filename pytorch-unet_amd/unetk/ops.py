@@ -313,6 +313,48 @@ def conv3x3_first_wgrad(x_f32, dy, dw):
     return dw
 
 
+def first_wgrad_bn_fusable(dtype):
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+def bn_relu_bwd_first_wgrad(dout, y, state, gamma, dgamma, dbeta, x_f32, dw, sums=None, frozen=False):
+    """BatchNorm+ReLU backward of the FIRST layer when its input needs no gradient: the conv-output gradient has one
+    reader, the weight-gradient kernel, which forms it on the fly from (dout, y) -- it is never stored.  Fills
+    dgamma/dbeta/dw with what bn_relu_bwd + conv3x3_first_wgrad give (bit for bit: same expression, same rounding).
+    sums: as in bn_relu_bwd."""
+    require_cuda(dout, y, x_f32, dw)
+    n, h, w, c, lddo = nhwc_meta(dout, 'bn grad input')
+    yn, yh, yw, yc, ldy = nhwc_meta(y, 'bn saved input')
+    xn, xh, xw, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    if (yn, yh, yw, yc) != (n, h, w, c) or (xn, xh, xw) != (n, h, w) or dout.dtype != y.dtype:
+        raise RuntimeError('bn_relu_bwd_first_wgrad: dout, y and the image must cover the same pixels')
+    if not first_wgrad_bn_fusable(y.dtype):
+        raise RuntimeError('bn_relu_bwd_first_wgrad: 16-bit activations only (use bn_relu_bwd + conv3x3_first_wgrad)')
+    dc = dtype_code(y.dtype)
+    npix = n * h * w
+    have_sums = sums is not None
+    if have_sums:
+        if sums.dtype != torch.float64 or sums.numel() != nat.STAT_REPLICAS * c * 2:
+            raise RuntimeError('bn_relu_bwd_first_wgrad: sums must be float64 [REPLICAS, C, 2]')
+    else:
+        sums = new_stats(c, y.device)
+        check(fn['unetk_bn_relu_bwd_reduce'](dout.data_ptr(), lddo, y.data_ptr(), ldy, state.scale.data_ptr(),
+                                             state.shift.data_ptr(), state.mean.data_ptr(), state.invstd.data_ptr(),
+                                             sums.data_ptr(), npix, c, dc, stream_ptr()), 'unetk_bn_relu_bwd_reduce')
+    coef = torch.empty((3, c), dtype=torch.float32, device=y.device)
+    _bn_bwd_finalize(sums, npix, gamma, state, dgamma, dbeta, coef, frozen)
+    run_deferred()           # the second layer's weight gradient: parameter gradients complete in layout order (unetk.ddp)
+    need = fn['unetk_conv3x3_first_wgrad_workspace_bytes'](n, h, w, c)
+    if need < 0:
+        check(int(need), 'unetk_conv3x3_first_wgrad_workspace_bytes')
+    ws = workspace(need, y.device)
+    check(fn['unetk_conv3x3_first_wgrad_bn'](x_f32.data_ptr(), ldx, dout.data_ptr(), lddo, y.data_ptr(), ldy,
+                                             state.scale.data_ptr(), state.shift.data_ptr(), state.mean.data_ptr(),
+                                             coef.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), n, h, w, c_in, c,
+                                             dc, stream_ptr()), 'unetk_conv3x3_first_wgrad_bn')
+    return dw
+
+
 def conv3x3_first_dgrad(dy, w_param, c_in):
     """Gradient w.r.t. the fp32 NHWC input image of the first layer: [N,H,W,c_in] fp32."""
     require_cuda(dy, w_param)

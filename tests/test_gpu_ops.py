@@ -109,6 +109,58 @@ def test_first_conv_wgrad_bf16(n, h, w, cin, dt16):
     assert rel_err(_np(dw), ref) < 1e-4
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 16, 23, 3, 64), (2, 11, 70, 1, 64), (1, 8, 32, 4, 128), (3, 9, 33, 3, 64)])
+@pytest.mark.parametrize('dt16', H16)
+def test_first_conv_wgrad_with_bn_backward(n, h, w, cin, cout, dt16):
+    """unetk_conv3x3_first_wgrad_bn (the conv-output gradient formed on the fly, never stored) against the two-kernel
+    sequence it replaces -- bit for bit -- and against the oracle's BatchNorm+ReLU backward + conv3x3 weight gradient."""
+    from oracle import ops_numpy as O
+    from unetk import ops
+    x = _rand((n, h, w, cin), 23, 0.5, 0.5).cuda()
+    z = _rand((n, h, w, cout), 27, 1.0, 0.3).to(dt16)
+    dout = _rand((n, h, w, cout), 28, 0.1).to(dt16)
+    bn = _BN(cout)
+    z64 = _np(z)
+    stats = ops.new_stats(cout, 'cuda')
+    stats[0, :, 0] = torch.from_numpy(z64.reshape(-1, cout).sum(0)).cuda()
+    stats[0, :, 1] = torch.from_numpy((z64 * z64).reshape(-1, cout).sum(0)).cuda()
+    st = ops.BNState(cout, 'cuda')
+    ops.bn_train_finalize(stats, n * h * w, bn, st, 0.1, 1e-5)
+    # the reduction pass once, for both (its fp64 atomics land in any order: two runs may differ in the last bit)
+    from unetk import _native as nat
+    sums = ops.new_stats(cout, 'cuda')
+    zc, dc_ = z.cuda(), dout.cuda()
+    nat.check(nat.fn['unetk_bn_relu_bwd_reduce'](dc_.data_ptr(), cout, zc.data_ptr(), cout, st.scale.data_ptr(),
+                                                 st.shift.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(),
+                                                 sums.data_ptr(), n * h * w, cout, nat.dtype_code(dt16), nat.stream_ptr()),
+              'unetk_bn_relu_bwd_reduce')
+    # the two-kernel sequence
+    dg0, db0 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    dy = ops.bn_relu_bwd(dc_, zc, st, bn.weight, dg0, db0, sums=sums.clone())
+    dw0 = torch.empty((cout, cin, 3, 3), device='cuda')
+    ops.conv3x3_first_wgrad(x, dy, dw0)
+    # fused, on channel slices of wider buffers (pitches differ from the channel count)
+    wide_d = torch.zeros((n, h, w, cout + 64), dtype=dt16, device='cuda')
+    wide_z = torch.zeros((n, h, w, cout + 128), dtype=dt16, device='cuda')
+    wide_d[..., 64:] = dout.cuda()
+    wide_z[..., 128:] = z.cuda()
+    dg1, db1 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    dw1 = torch.full((cout, cin, 3, 3), 7.0, device='cuda')
+    ops.bn_relu_bwd_first_wgrad(wide_d[..., 64:], wide_z[..., 128:], st, bn.weight, dg1, db1, x, dw1, sums=sums.clone())
+    assert torch.equal(dw1, dw0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    # ... and with its own reduction pass
+    dw2 = torch.empty_like(dw1)
+    ops.bn_relu_bwd_first_wgrad(wide_d[..., 64:], wide_z[..., 128:], st, bn.weight, dg1, db1, x, dw2)
+    assert rel_err(_np(dw2), _np(dw0)) < 1e-3 and rel_err(_np(dg1), _np(dg0)) < 1e-5
+    # oracle
+    zn, mean, var, invstd = O.bn_train_fwd(z64, _np(bn.weight), _np(bn.bias))
+    dy_ref, _, _ = O.bn_relu_train_bwd(z64, _np(bn.weight), mean, invstd, O.relu(zn), _np(dout))
+    _, ref = O.conv3x3_bwd(_np(x.to(dt16)), np.zeros((cout, cin, 3, 3)), dy_ref)
+    assert rel_err(_np(dw1), ref) < TOL[dt16]          # the kernel rounds dy to the 16-bit type, as the stored one was
+    with pytest.raises(RuntimeError):
+        ops.bn_relu_bwd_first_wgrad(dout.float().cuda(), z.float().cuda(), st, bn.weight, dg1, db1, x, dw1)
+
+
 # --------------------------------------------------------------------------------------- transposed conv
 @pytest.mark.parametrize('dtype', BOTH)
 @pytest.mark.parametrize('n,h,w,cin,hs,ws', [(2, 8, 11, 128, 17, 23), (1, 4, 5, 128, 11, 13), (1, 9, 33, 256, 18, 66)])
