@@ -372,6 +372,15 @@ def main(argv=None):
                 if mb:
                     roofline['mfma_busy_counters'] = mb['value']
                     roofline['mfma_busy_source'] = mb['source']
+            if dtype_name == 'bf16' and dom != 'conv3x3_db_kernel':
+                # a measured-on-box matrix-pipe peak beside the nominal one -- the instruction this kernel
+                # issues, back to back from registers on random operands (scripts/microbench/mfma_peak.hip)
+                pk = committed_profile('*_mfma_peak.json', lambda d: d.get('v_mfma_f32_16x16x32_bf16', {})
+                                       .get('random', {}).get('steady_median_tflops'))
+                if pk:
+                    roofline['peak_measured'] = pk['value']
+                    roofline['frac_of_measured'] = achieved / pk['value']
+                    roofline['peak_measured_source'] = pk['source']
         fams = kt.by_hbm_family()
         if fams:
             peak_gbs = 8000.0                              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
