@@ -100,6 +100,14 @@ int unetk_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float*
  * Reads the fp32 NHWC image directly (train.py:97 hands over fp32 channels_last) and the UNPACKED parameter. */
 int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
                               int wd, int c_in, int c_out, int dtype, void* stream);
+/* Training-mode forward of the layer with its BatchNorm2d + ReLU (unet_parts.py:16-18 at unet_model.py:13) without reading
+ * the 64-channel output back: call unetk_conv3x3_first_fprop with y = NULL (statistics only: the sums are those of the
+ * output rounded to `dtype`, nothing is stored), unetk_bn_train_finalize, then this entry point, which computes the
+ * layer again and stores y (saved for backward) together with act = relu(scale[c] * y + shift[c]) formed from the
+ * ROUNDED y -- the same bits as unetk_conv3x3_first_fprop + unetk_bn_relu_apply. */
+int unetk_conv3x3_first_fprop_bn_relu_train(const float* x, int ldx, const float* w, const float* scale,
+                                            const float* shift, void* y, int ldy, void* act, int lda, int n, int h, int wd,
+                                            int c_in, int c_out, int dtype, void* stream);
 /* Same layer under net.eval() (evaluate.py:10, predict.py:20): y = relu(scale[c] * conv + shift[c]), the eval-mode
  * BatchNorm2d + ReLU of unet_parts.py:17-18 folded into the store (scale/shift from unetk_bn_eval_params). */
 int unetk_conv3x3_first_fprop_bn_relu(const float* x, int ldx, const float* w, const float* scale, const float* shift,

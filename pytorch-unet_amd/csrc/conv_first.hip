@@ -23,9 +23,15 @@ struct FirstParams {
   const float* aff_shift;
   int N, H, W, Cin, Cout, ldx, ldy;
   int tiles_x, tiles_y, n_tiles;
+  void* act;                // MODE 2: relu(scale[c] * y + shift[c]) of the ROUNDED y (pitch lda)
+  int lda;
 };
 
-template <typename T>
+// MODE 0: y (+ statistics), or the eval-mode fused form (aff_scale != NULL).
+// MODE 1: statistics only -- nothing is stored.  MODE 2: y and the training-mode BatchNorm + ReLU of it, the arithmetic
+// of bn_relu_apply on the stored (rounded) y.  Training runs 1, finalize, 2: the layer is so cheap (27 MACs per output,
+// 12 bytes read per pixel) that computing it twice costs less than reading its 64-channel output back for the apply pass.
+template <typename T, int MODE = 0>
 __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int NB = 2, BN = 64;
@@ -61,12 +67,12 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
   }
 
   const int ch0 = nt * BN + NB * j;
-  const bool aff = P.aff_scale != nullptr;
+  const bool aff = MODE == 0 && P.aff_scale != nullptr;
   float asc[NB], ash[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    asc[nb] = aff ? P.aff_scale[ch0 + nb] : 1.f;
-    ash[nb] = aff ? P.aff_shift[ch0 + nb] : 0.f;
+    asc[nb] = P.aff_scale != nullptr ? P.aff_scale[ch0 + nb] : 1.f;
+    ash[nb] = P.aff_scale != nullptr ? P.aff_shift[ch0 + nb] : 0.f;
   }
   // BN statistics across this workgroup's tiles: fp32 for bf16 tensors, fp64 for fp32 tensors (conv_igemm.hip)
   using StatAcc = typename std::conditional<sizeof(T) == 4, double, float>::type;
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
     // 64-bit address arithmetic once per row (wave-uniform); an element adds a 32-bit lane offset and a compile-time
     // multiple of the pixel pitch (as in conv3x3_db_kernel)
     T* yimg = reinterpret_cast<T*>(P.y) + (size_t)img * P.H * P.W * P.ldy;
+    T* aimg = reinterpret_cast<T*>(P.act) + (size_t)img * P.H * P.W * P.lda;
     const int lane_off = 4 * h * P.ldy + ch0;
+    const int lane_off_a = 4 * h * P.lda + ch0;
     const int xl = x0 + 4 * h;
     bool done = false;
     if constexpr (sizeof(T) == 2) {
@@ -176,21 +184,36 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
         for (int mb = 0; mb < 2; ++mb) {
           const int yy = y0 + 2 * wid + mb;
           T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy + lane_off;
+          T* rowa = aimg + (size_t)(yy * P.W + x0) * P.lda + lane_off_a;
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
             const int ri = (i & 3) + 8 * (i >> 2);
-            unsigned pk[NB];
+            unsigned pk[NB], ak[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
               const h2 y2 = {(T)acc[mb][nb][i], (T)acc[mb][nb][i + 1]};
               pk[nb] = __builtin_bit_cast(unsigned, y2);
-              ssum[nb] = H16<T>::dot2(y2, one2, ssum[nb]);
-              ssq[nb] = H16<T>::dot2(y2, y2, ssq[nb]);
+              if constexpr (MODE != 2) {
+                ssum[nb] = H16<T>::dot2(y2, one2, ssum[nb]);
+                ssq[nb] = H16<T>::dot2(y2, y2, ssq[nb]);
+              } else {
+                const h2 a2 = {(T)fmaxf(fmaf((float)y2[0], asc[nb], ash[nb]), 0.f),
+                               (T)fmaxf(fmaf((float)y2[1], asc[nb], ash[nb]), 0.f)};
+                ak[nb] = __builtin_bit_cast(unsigned, a2);
+              }
             }
-            __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x05040100u),
-                                        reinterpret_cast<unsigned*>(rowp + ri * P.ldy));
-            __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x07060302u),
-                                        reinterpret_cast<unsigned*>(rowp + (ri + 1) * P.ldy));
+            if constexpr (MODE != 1) {
+              __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x05040100u),
+                                          reinterpret_cast<unsigned*>(rowp + ri * P.ldy));
+              __builtin_nontemporal_store(__builtin_amdgcn_perm(pk[1], pk[0], 0x07060302u),
+                                          reinterpret_cast<unsigned*>(rowp + (ri + 1) * P.ldy));
+            }
+            if constexpr (MODE == 2) {
+              __builtin_nontemporal_store(__builtin_amdgcn_perm(ak[1], ak[0], 0x05040100u),
+                                          reinterpret_cast<unsigned*>(rowa + ri * P.lda));
+              __builtin_nontemporal_store(__builtin_amdgcn_perm(ak[1], ak[0], 0x07060302u),
+                                          reinterpret_cast<unsigned*>(rowa + (ri + 1) * P.lda));
+            }
           }
         }
         done = true;
@@ -201,19 +224,22 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
       if (done) break;
       const int yy = y0 + 2 * wid + mb;
       T* rowp = yimg + (size_t)(yy * P.W + x0) * P.ldy;
+      T* rowa = aimg + (size_t)(yy * P.W + x0) * P.lda;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ri = (i & 3) + 8 * (i >> 2);
         if (yy < P.H && xl + ri < P.W) {
-          float v[NB];
+          float v[NB], a[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             const float f = to_f32(from_f32<T>(acc[mb][nb][i]));
             v[nb] = aff ? fmaxf(fmaf(acc[mb][nb][i], asc[nb], ash[nb]), 0.f) : f;
+            a[nb] = fmaxf(fmaf(f, asc[nb], ash[nb]), 0.f);
             ssum[nb] += f;
             ssq[nb] += f * f;
           }
-          store_channels<T, NB>(rowp + ri * P.ldy + lane_off, v);
+          if constexpr (MODE != 1) store_channels<T, NB>(rowp + ri * P.ldy + lane_off, v);
+          if constexpr (MODE == 2) store_channels<T, NB>(rowa + ri * P.lda + lane_off_a, a);
         }
       }
     }
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_fprop_kernel(FirstParams P)
     for (int nb = 0; nb < NB; ++nb) { tsum[nb] += (StatAcc)ssum[nb]; tsq[nb] += (StatAcc)ssq[nb]; }
   }
 
-  if (P.stats != nullptr && !aff) {
+  if (MODE != 2 && P.stats != nullptr && !aff) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       tsum[nb] += __shfl_xor(tsum[nb], 32, 64);
@@ -636,16 +662,29 @@ __global__ __launch_bounds__(256) void conv_first_dgrad_kernel(const T* __restri
 
 extern "C" {
 
+// mode: the kernel's MODE (1: y may be NULL; 2: act / lda give the activation's buffer)
 static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, const float* scale,
-                       const float* shift, int n, int h, int wd, int c_in, int c_out, int dtype, void* stream) {
-  if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
+                       const float* shift, int n, int h, int wd, int c_in, int c_out, int dtype, void* stream,
+                       int mode = 0, void* act = nullptr, int lda = 0) {
+  if (!x || !w || n <= 0 || h <= 0 || wd <= 0) return UNETK_ERR_ARG;
+  if (mode == 1 ? !stats : !y) return UNETK_ERR_ARG;
   if (!unetk_dtype_ok(dtype)) return UNETK_ERR_DTYPE;
-  if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || ldx < c_in || ldy < c_out) return UNETK_ERR_SHAPE;
+  if (c_in < 1 || c_in > 4 || c_out % 64 || c_out <= 0 || ldx < c_in) return UNETK_ERR_SHAPE;
   const int es = unetk_esize(dtype);
-  if ((reinterpret_cast<uintptr_t>(y) & 15) || (ldy * es) % 16) return UNETK_ERR_ALIGN;
-  if ((long)h * wd * ldy >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+  if (mode != 1) {
+    if (ldy < c_out) return UNETK_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(y) & 15) || (ldy * es) % 16) return UNETK_ERR_ALIGN;
+    if ((long)h * wd * ldy >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+  } else {
+    y = nullptr; ldy = c_out;
+  }
+  if (mode == 2) {
+    if (!act || !scale || !shift) return UNETK_ERR_ARG;
+    if (lda < c_out || (long)h * wd * lda >= 0x7fffffffL) return UNETK_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(act) & 15) || (lda * es) % 16) return UNETK_ERR_ALIGN;
+  }
   FirstParams P{};
-  P.x = x; P.w = w; P.y = y; P.stats = stats; P.aff_scale = scale; P.aff_shift = shift;
+  P.x = x; P.w = w; P.y = y; P.stats = stats; P.aff_scale = scale; P.aff_shift = shift; P.act = act; P.lda = lda;
   P.N = n; P.H = h; P.W = wd; P.Cin = c_in; P.Cout = c_out; P.ldx = ldx; P.ldy = ldy;
   P.tiles_x = host_cdiv(wd, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = c_out / 64;
   const long spatial = (long)n * P.tiles_x * P.tiles_y;
@@ -654,14 +693,26 @@ static int first_fprop(const float* x, int ldx, const float* w, void* y, int ldy
   const long groups = spatial < 2048 ? spatial : 2048;
   const long nblk = groups * P.n_tiles;
   const size_t lds = 340 * 16 + 5 * 2 * 1024;
-  UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv_first_fprop_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P));
+  if (mode == 1) {
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL((conv_first_fprop_kernel<T, 1>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P));
+  } else if (mode == 2) {
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL((conv_first_fprop_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P));
+  } else {
+    UNETK_WITH_T(dtype, hipLaunchKernelGGL(conv_first_fprop_kernel<T>, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, P));
+  }
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
 
 int unetk_conv3x3_first_fprop(const float* x, int ldx, const float* w, void* y, int ldy, double* stats, int n, int h,
                               int wd, int c_in, int c_out, int dtype, void* stream) {
-  return first_fprop(x, ldx, w, y, ldy, stats, nullptr, nullptr, n, h, wd, c_in, c_out, dtype, stream);
+  return first_fprop(x, ldx, w, y, ldy, stats, nullptr, nullptr, n, h, wd, c_in, c_out, dtype, stream, y ? 0 : 1);
+}
+
+int unetk_conv3x3_first_fprop_bn_relu_train(const float* x, int ldx, const float* w, const float* scale,
+                                            const float* shift, void* y, int ldy, void* act, int lda, int n, int h, int wd,
+                                            int c_in, int c_out, int dtype, void* stream) {
+  return first_fprop(x, ldx, w, y, ldy, nullptr, scale, shift, n, h, wd, c_in, c_out, dtype, stream, 2, act, lda);
 }
 
 int unetk_conv3x3_first_fprop_bn_relu(const float* x, int ldx, const float* w, const float* scale, const float* shift,

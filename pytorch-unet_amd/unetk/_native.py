@@ -118,6 +118,8 @@ class KernelTimer:
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
         if name == 'unetk_conv3x3_first_fprop':
             return 2.0 * a[6] * a[7] * a[8] * 9 * a[9] * a[10]
+        if name == 'unetk_conv3x3_first_fprop_bn_relu_train':
+            return 2.0 * a[9] * a[10] * a[11] * 9 * a[12] * a[13]
         if name == 'unetk_conv3x3_first_wgrad':
             return 2.0 * a[7] * a[8] * a[9] * 9 * a[10] * a[11]
         if name == 'unetk_conv3x3_first_wgrad_bn':
@@ -193,9 +195,12 @@ class KernelTimer:
         if name == 'unetk_convT2x2_wgrad':                    # read x and the up-sampled gradient, write fp32 dw
             n, h, w, ci, co = a[8:13]
             return 'convT_wgrad', 1.0 * n * h * w * (ci + 4 * co) * es(a[18]) + 16.0 * ci * co
-        if name == 'unetk_conv3x3_first_fprop':               # read the fp32 image, write c_out channels
+        if name == 'unetk_conv3x3_first_fprop':               # read the fp32 image, write c_out channels (y may be NULL)
             n, h, w, ci, co = a[6:11]
-            return 'first_layer', 1.0 * n * h * w * (4 * ci + co * es(a[11]))
+            return 'first_layer', 1.0 * n * h * w * (4 * ci + (co * es(a[11]) if a[3] else 0))
+        if name == 'unetk_conv3x3_first_fprop_bn_relu_train':  # read the image, write y and the activation
+            n, h, w, ci, co = a[9:14]
+            return 'first_layer', 1.0 * n * h * w * (4 * ci + 2 * co * es(a[14]))
         if name == 'unetk_conv3x3_first_wgrad':               # read the image and dy
             n, h, w, ci, co = a[7:12]
             return 'first_layer', 1.0 * n * h * w * (4 * ci + co * es(a[12]))

@@ -158,9 +158,15 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
         if pool_out is not None:
             ops.maxpool_into(act, pool_out)
         return act, (x, None, st)
+    # the first layer in training: statistics pass, finalize, then the layer again with BatchNorm + ReLU in its epilogue
+    # (its 64-channel output is written once and not read back for an apply pass)
+    first_fused = c_in <= 4 and FUSE_FIRST_FWD and pool_out is None and head is None
     if c_in <= 4:
         xin = x if x.dtype == torch.float32 else x.float()
-        y = ops.conv3x3_first_fprop(xin, _f32c(conv.weight), c_out, dtype, stats=stats)
+        if not first_fused:
+            y = ops.conv3x3_first_fprop(xin, _f32c(conv.weight), c_out, dtype, stats=stats)
+        elif batch_stats:
+            ops.conv3x3_first_stats(xin, _f32c(conv.weight), c_out, dtype, stats)
         x = xin
     else:
         if x.dtype != dtype:
@@ -181,6 +187,9 @@ def conv_bn_relu_fwd(conv, bn, x, dtype, out=None, pool_out=None, head=None):
         ops.bn_train_finalize(stats, n * h * w, _B, st, float(momentum or 0.0), float(bn.eps))
     else:
         ops.bn_eval_params(bn, st, float(bn.eps), for_backward=SAVING_FOR_BACKWARD)
+    if first_fused:
+        y, act = ops.conv3x3_first_fprop_bn_relu_train(x, _f32c(conv.weight), c_out, dtype, st, out=out)
+        return act, (x, y, st)
     if head is not None and pool_out is None and ops.head_fwd_fusable(c_out, head['conv'].out_channels, dtype) \
             and head['conv'].kernel_size == (1, 1):
         hc = head['conv']
@@ -206,6 +215,9 @@ DEFER_WGRAD_ENABLED = os.environ.get('UNETK_DEFER_WGRAD', '1') != '0'
 
 # UNETK_HEAD_STORE_ACT=1 (A/B runs): the whole-net forward stores the last activation although nothing reads it
 HEAD_STORE_ACT = os.environ.get('UNETK_HEAD_STORE_ACT', '0') != '0'
+
+# UNETK_FUSE_FIRST_FWD=0 (A/B runs): the first layer's forward stays conv (+ statistics), finalize, apply pass
+FUSE_FIRST_FWD = os.environ.get('UNETK_FUSE_FIRST_FWD', '1') != '0'
 
 # UNETK_FUSE_FIRST_WGRAD=0 (A/B runs): the first layer's BatchNorm-backward apply pass and weight gradient stay two kernels
 FUSE_FIRST_WGRAD = os.environ.get('UNETK_FUSE_FIRST_WGRAD', '1') != '0'

@@ -283,6 +283,38 @@ def conv3x3_first_fprop(x_f32, w_param, c_out, dtype, out=None, stats=None):
     return out
 
 
+def conv3x3_first_stats(x_f32, w_param, c_out, dtype, stats):
+    """The first layer's BatchNorm statistics (sums of its output rounded to `dtype`) without storing the output."""
+    require_cuda(x_f32, w_param, stats)
+    n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    if x_f32.dtype != torch.float32 or w_param.dtype != torch.float32 or not w_param.is_contiguous():
+        raise RuntimeError('first conv: image and parameter must be fp32')
+    check(fn['unetk_conv3x3_first_fprop'](x_f32.data_ptr(), ldx, w_param.data_ptr(), None, c_out, stats.data_ptr(),
+                                          n, h, w, c_in, c_out, dtype_code(dtype), stream_ptr()),
+          'unetk_conv3x3_first_fprop')
+    return stats
+
+
+def conv3x3_first_fprop_bn_relu_train(x_f32, w_param, c_out, dtype, state, out=None):
+    """The first layer computed again with its BatchNorm + ReLU applied: returns (y, act) -- y is what
+    conv3x3_first_fprop stores (saved for backward), act what bn_relu_apply makes of it, bit for bit."""
+    require_cuda(x_f32, w_param)
+    n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')
+    if x_f32.dtype != torch.float32 or w_param.dtype != torch.float32 or not w_param.is_contiguous():
+        raise RuntimeError('first conv: image and parameter must be fp32')
+    y = new_nhwc(n, h, w, c_out, dtype, x_f32.device)
+    if out is None:
+        out = new_nhwc(n, h, w, c_out, dtype, x_f32.device)
+    on, oh, ow, oc, lda = nhwc_meta(out, 'first conv activation')
+    if (on, oh, ow, oc) != (n, h, w, c_out) or out.dtype != dtype or state.scale.numel() != c_out:
+        raise RuntimeError('first conv: output / BatchNorm coefficients do not match')
+    check(fn['unetk_conv3x3_first_fprop_bn_relu_train'](x_f32.data_ptr(), ldx, w_param.data_ptr(), state.scale.data_ptr(),
+                                                        state.shift.data_ptr(), y.data_ptr(), c_out, out.data_ptr(), lda,
+                                                        n, h, w, c_in, c_out, dtype_code(dtype), stream_ptr()),
+          'unetk_conv3x3_first_fprop_bn_relu_train')
+    return y, out
+
+
 def conv3x3_first_fprop_bn_relu(x_f32, w_param, c_out, dtype, state, out=None):
     require_cuda(x_f32, w_param)
     n, h, w, c_in, ldx = nhwc_meta(x_f32, 'first conv input')

@@ -34,3 +34,14 @@ gb = (x.numel() * 4 + y.numel() * 2) / 1e9
 print(f'first fprop: {t:.3f} ms  {gb / t:.2f} TB/s of {gb:.2f} GB')
 t = timeit(lambda: ops.conv3x3_first_wgrad(x, dy, dw))
 print(f'first wgrad: {t:.3f} ms  {gb / t:.2f} TB/s of {gb:.2f} GB')
+
+# training forward: conv (+ statistics) then the apply pass, against statistics-only pass + conv with BN + ReLU
+st = ops.BNState(64, 'cuda')
+st.scale.fill_(0.7); st.shift.fill_(0.1)
+act = torch.empty_like(y)
+out = torch.empty_like(y)
+t1 = timeit(lambda: ops.conv3x3_first_fprop(x, wt, 64, torch.bfloat16, out=y, stats=stats))
+t2 = timeit(lambda: ops.bn_relu_apply(y, st, out=act))
+t3 = timeit(lambda: ops.conv3x3_first_stats(x, wt, 64, torch.bfloat16, stats))
+t4 = timeit(lambda: ops.conv3x3_first_fprop_bn_relu_train(x, wt, 64, torch.bfloat16, st, out=out))
+print(f'forward: conv+stats {t1:.3f} + apply {t2:.3f} = {t1 + t2:.3f} ms | stats only {t3:.3f} + conv+BN+ReLU {t4:.3f} = {t3 + t4:.3f} ms')

@@ -96,6 +96,30 @@ def test_first_conv_fprop(dtype, n, h, w, cin):
     assert np.allclose(s[:, 1], (got * got).reshape(-1, 64).sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 16, 23, 3, 64), (1, 9, 40, 1, 64), (2, 24, 64, 4, 128), (1, 1, 1, 3, 64)])
+def test_first_conv_two_pass_training_forward(dtype, n, h, w, cin, cout):
+    """Statistics-only pass + unetk_conv3x3_first_fprop_bn_relu_train against the sequence they replace
+    (unetk_conv3x3_first_fprop with statistics, unetk_bn_relu_apply): y and the activation bit for bit, the sums to fp64
+    rounding (their atomics land in any order)."""
+    from unetk import ops
+    x = _rand((n, h, w, cin), 21, 0.5, 0.5).cuda()
+    wt = _rand((cout, cin, 3, 3), 22, 0.3).cuda()
+    bn = _BN(cout)
+    s0 = ops.new_stats(cout, 'cuda')
+    y0 = ops.conv3x3_first_fprop(x, wt, cout, dtype, stats=s0)
+    st = ops.BNState(cout, 'cuda')
+    ops.bn_train_finalize(s0, n * h * w, bn, st, 0.1, 1e-5)
+    act0 = ops.bn_relu_apply(y0, st)
+    s1 = ops.new_stats(cout, 'cuda')
+    ops.conv3x3_first_stats(x, wt, cout, dtype, s1)
+    assert torch.allclose(s1.sum(0), s0.sum(0), rtol=1e-12, atol=1e-9)
+    wide = torch.full((n, h, w, cout + 64), 3.0, dtype=dtype, device='cuda')      # activation into a channel slice
+    y1, act1 = ops.conv3x3_first_fprop_bn_relu_train(x, wt, cout, dtype, st, out=wide[..., 64:])
+    assert torch.equal(y1, y0) and torch.equal(act1, act0)
+    assert bool((wide[..., :64] == 3.0).all())
+
+
 @pytest.mark.parametrize('n,h,w,cin', [(2, 16, 23, 3), (2, 11, 70, 1)])
 @pytest.mark.parametrize('dt16', H16)
 def test_first_conv_wgrad_bf16(n, h, w, cin, dt16):
