@@ -804,12 +804,13 @@ int launch_db(const ConvParams& P, hipStream_t s) {
 // NW / KS: 8 waves and 64-channel chunks (160 KiB: one workgroup per CU), or -- the shallow, HBM-bound levels -- 4 waves
 // and 32-channel chunks (48 KiB): then two or three INDEPENDENT workgroups share a CU and one's epilogue stores run
 // under another's DMA and MFMA phases.  The packed weight stream is the same for both (k-steps in order, NB inner).
-template <typename T, int MODE, int NW = 8, int KS = 4>
+template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2>
 __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
+  constexpr int LA = NBUF - 1;                    // chunks of DMA look-ahead
   constexpr int E = ElemTraits<T>::E;
   constexpr int NB = 4;
   constexpr int NP = 2 * KS, CH = NP * E, S = 32 * KS;
-  constexpr int TP = 64 * NW;                     // pixels per tile
+  constexpr int TP = 32 * MBS * NW;               // pixels per tile (MBS 32-pixel row blocks per wave)
   constexpr int IN_INSTR = TP * S / 1024;         // 64
   constexpr int IN_BYTES = IN_INSTR * 1024;
   constexpr int WFRAGS = KS * NB;                 // 16
@@ -842,10 +843,10 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
   const char* xbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(P.x) + P.xoff);
   const int HW = P.H * P.W;
 
-  int aaddr[2];
+  int aaddr[MBS];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int p = (2 * wid + mb) * 32 + j;
+  for (int mb = 0; mb < MBS; ++mb) {
+    const int p = (MBS * wid + mb) * 32 + j;
     aaddr[mb] = p * S + ((h ^ ((p >> 1) & (NP - 1))) << 4);
   }
 
@@ -893,9 +894,9 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
     }
   };
 
-  f32x16 acc[2][NB];
+  f32x16 acc[MBS][NB];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MBS; ++mb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -913,26 +914,31 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
 
   setup_stage(tile_begin);
   const unsigned lds0 = lds_address(smem);
+  // the first LA chunks of the first tile (the launcher guarantees niter >= LA)
 #pragma unroll
-  for (int q = 0; q < NDMA; ++q) issue_piece(q, 0, 0, lds0, true);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int c = 0; c < LA; ++c)
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) issue_piece(q, c, iter_bytes(c), lds0 + c * BUF, true);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA * (LA - 1)) : "memory");
   int cur = 0;
 
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int it = 0; it < niter; ++it) {
       const char* lds_in = smem + cur * BUF;
       const char* lds_w = lds_in + IN_BYTES;
-      const bool last_it = it + 1 == niter;
-      const bool live = (!last_it || tile + 1 < tile_end) && !(P.dbg & 1);
-      if (last_it && live) setup_stage(tile + 1);
-      const int nit = last_it ? 0 : it + 1;
+      // the chunk issued during this one lies LA chunks ahead, possibly in the next tile
+      const bool wraps = it + LA >= niter;
+      const bool live = (!wraps || tile + 1 < tile_end) && !(P.dbg & 1);
+      if (it + LA == niter && live) setup_stage(tile + 1);
+      const int nit = wraps ? it + LA - niter : it + LA;
       const long nib = iter_bytes(nit);
-      const unsigned nbuf = lds0 + (cur ^ 1) * BUF;
+      const int nidx = cur + LA >= NBUF ? cur + LA - NBUF : cur + LA;
+      const unsigned nbuf = lds0 + nidx * BUF;
 
-      uint4 fa[2][2], fb[2][NB];
-      auto load_frags = [&](int ks, uint4 (&a)[2], uint4 (&b)[NB]) {
+      uint4 fa[2][MBS], fb[2][NB];
+      auto load_frags = [&](int ks, uint4 (&a)[MBS], uint4 (&b)[NB]) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb] ^ (ks << 5)));
+        for (int mb = 0; mb < MBS; ++mb) a[mb] = *reinterpret_cast<const uint4*>(lds_in + (aaddr[mb] ^ (ks << 5)));
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           b[nb] = *reinterpret_cast<const uint4*>(lds_w + (ks * NB + nb) * 1024 + lane * 16);
@@ -944,18 +950,20 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
 #pragma unroll
         for (int q = ks * PPS; q < (ks + 1) * PPS && q < NDMA; ++q) issue_piece(q, nit, nib, nbuf, live);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MBS; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) Mma<T>::run(acc[mb][nb], fa[ks & 1][mb], fb[ks & 1][nb]);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      cur ^= 1;
+      // the chunk issued LA - 1 iterations ago must have landed; the newest LA - 1 chunks (and nothing older: vmcnt
+      // retires in issue order, epilogue stores included) may stay in flight
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA * (LA - 1)) : "memory");
+      cur = cur + 1 == NBUF ? 0 : cur + 1;
     }
 
     // ---- epilogue
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const long gb = (long)tile * TP + (2 * wid + mb) * 32;       // wave-uniform
+    for (int mb = 0; mb < MBS; ++mb) {
+      const long gb = (long)tile * TP + (MBS * wid + mb) * 32;       // wave-uniform
       // 64-bit address arithmetic once per row block (wave-uniform); per element a 32-bit element offset
       if constexpr (MODE == 1) {
         const int img0 = (int)(gb / HW), r0 = (int)(gb - (long)img0 * HW);
@@ -1053,14 +1061,15 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
   }
 }
 
-template <typename T, int MODE, int NW = 8, int KS = 4> int launch_pw(const ConvParams& P, hipStream_t s) {
-  constexpr size_t lds = 2 * ((size_t)64 * NW * 32 * KS + KS * 4 * 1024);
+template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2> int launch_pw(const ConvParams& P, hipStream_t s) {
+  constexpr int TP = 32 * MBS * NW;
+  constexpr size_t lds = NBUF * ((size_t)TP * 32 * KS + KS * 4 * 1024);
   constexpr int WG_PER_CU = NW == 8 ? 1 : (160 * 1024) / (int)lds > 2 ? 2 : (160 * 1024) / (int)lds;   // VGPRs: 8 waves per CU
-  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS>), lds);
+  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS>), lds);
   ConvParams Q = P;
   Q.n_tiles = P.Cout / 128;
   const long npix = (long)P.N * P.H * P.W;
-  const long ntiles = (npix + 64 * NW - 1) / (64 * NW);
+  const long ntiles = (npix + TP - 1) / TP;
   const int niter = (P.Cin / (2 * KS * ElemTraits<T>::E)) * (MODE == 2 ? 4 : 1);
   // tiles per workgroup by the round model of launch_db (whole rounds of resident workgroups)
   int tpb = 1;
@@ -1086,7 +1095,7 @@ template <typename T, int MODE, int NW = 8, int KS = 4> int launch_pw(const Conv
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
   Q.nblk = (int)nblk;
-  hipLaunchKernelGGL((pw_db_kernel<T, MODE, NW, KS>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(64 * NW), lds, s, Q);
+  hipLaunchKernelGGL((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(64 * NW), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -1160,8 +1169,26 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       // 0.35 -> 0.31, 0.23 -> 0.20, 0.22 -> 0.21 ms; dgrad 0.42 -> 0.40, 0.30 -> 0.29 ms; K = 2048 dgrad 0.21 -> 0.22)
       UNETK_KNOB(small, "UNETK_PW_SMALL", 1024);
       const bool few_k = P.Cin * (MODE == 2 ? 4 : 1) <= small;
+      // round 3: three buffers, two chunks of DMA look-ahead for the 4-wave form (a 32-channel chunk is 0.27 us of MFMA
+      // work, far less than a memory round trip): forward 1.135 -> 1.07 ms, dgrad 1.14 -> 1.05 ms over the four levels
+      UNETK_KNOB(nbuf, "UNETK_PW_NBUF", 3);
+#ifdef UNETK_TUNING
+      UNETK_KNOB(var, "UNETK_PW_VAR", 0);
+      if (dtype == UNETK_BF16 && var == 1) return launch_pw<bf16, MODE, 4, 4, 3>(P, s);      // full lines, 1 WG/CU
+      if (dtype == UNETK_BF16 && var == 2) return launch_pw<bf16, MODE, 8, 4, 3, 1>(P, s);   // full lines, 8 x 32 px
+      if (dtype == UNETK_BF16 && var == 3) return launch_pw<bf16, MODE, 8, 4, 2, 1>(P, s);
+#endif
+      if (few_k && nbuf == 3) {
+        if (dtype == UNETK_BF16) return launch_pw<bf16, MODE, 4, 2, 3>(P, s);
+        if (dtype == UNETK_F16) return launch_pw<f16, MODE, 4, 2, 3>(P, s);
+      }
+#ifdef UNETK_TUNING
       if (dtype == UNETK_BF16) return few_k ? launch_pw<bf16, MODE, 4, 2>(P, s) : launch_pw<bf16, MODE>(P, s);
       if (dtype == UNETK_F16) return few_k ? launch_pw<f16, MODE, 4, 2>(P, s) : launch_pw<f16, MODE>(P, s);
+#else
+      if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
+      if (dtype == UNETK_F16) return launch_pw<f16, MODE>(P, s);
+#endif
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
       return UNETK_ERR_DTYPE;
     }
