@@ -805,7 +805,7 @@ int launch_db(const ConvParams& P, hipStream_t s) {
 // and 32-channel chunks (48 KiB): then two or three INDEPENDENT workgroups share a CU and one's epilogue stores run
 // under another's DMA and MFMA phases.  The packed weight stream is the same for both (k-steps in order, NB inner).
 template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2>
-__global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
+__global__ __launch_bounds__(64 * NW, (MBS == 1 && KS == 2 ? 4 : 2)) void pw_db_kernel(ConvParams P) {
   constexpr int LA = NBUF - 1;                    // chunks of DMA look-ahead
   constexpr int E = ElemTraits<T>::E;
   constexpr int NB = 4;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pw_db_kernel(ConvParams P) {
 template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2> int launch_pw(const ConvParams& P, hipStream_t s) {
   constexpr int TP = 32 * MBS * NW;
   constexpr size_t lds = NBUF * ((size_t)TP * 32 * KS + KS * 4 * 1024);
-  constexpr int WG_PER_CU = NW == 8 ? 1 : (160 * 1024) / (int)lds > 2 ? 2 : (160 * 1024) / (int)lds;   // VGPRs: 8 waves per CU
+  constexpr int WG_PER_CU = (NW == 8 && !(MBS == 1 && KS == 2)) ? 1 : (160 * 1024) / (int)lds > 2 ? 2 : (160 * 1024) / (int)lds;   // VGPRs: 8 waves per CU
   UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS>), lds);
   ConvParams Q = P;
   Q.n_tiles = P.Cout / 128;
@@ -1165,30 +1165,25 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
   }
   if constexpr (MODE != 0) {
     if (pw_nb(P.Cout) == 4) {     // the packer made the same choice (conv_config.h)
-      // GEMM-K up to 1024: 4-wave workgroups, two per CU (measured at the four decoder levels: forward 0.48 -> 0.41,
-      // 0.35 -> 0.31, 0.23 -> 0.20, 0.22 -> 0.21 ms; dgrad 0.42 -> 0.40, 0.30 -> 0.29 ms; K = 2048 dgrad 0.21 -> 0.22)
+      // 16-bit types: 8 waves x ONE 32-pixel row block (256-pixel tiles), 64-channel chunks, three 48-KiB buffers with two
+      // chunks of DMA look-ahead.  What the ablations of rounds 2-3 say about these HBM/fill-bound GEMMs: a chunk is
+      // 0.3-0.5 us of MFMA work, less than a memory round trip, so one chunk of look-ahead leaves the fill path idle
+      // after every barrier (two buffers -> three: -6..-8 %); and the fill rate per CU follows the number of cache LINES
+      // in flight, so a DMA piece should use whole 128-byte lines (64 channels per pixel and chunk; the 32-channel
+      // chunks of the round-2 4-wave form fetched every line twice, half a line each: -1..-11 % more).  Over the four
+      // decoder levels, same box: forward 1.135 -> 1.03 ms, dgrad 1.14 -> 0.975 ms.
+#ifdef UNETK_TUNING
       UNETK_KNOB(small, "UNETK_PW_SMALL", 1024);
       const bool few_k = P.Cin * (MODE == 2 ? 4 : 1) <= small;
-      // round 3: three buffers, two chunks of DMA look-ahead for the 4-wave form (a 32-channel chunk is 0.27 us of MFMA
-      // work, far less than a memory round trip): forward 1.135 -> 1.07 ms, dgrad 1.14 -> 1.05 ms over the four levels
-      UNETK_KNOB(nbuf, "UNETK_PW_NBUF", 3);
-#ifdef UNETK_TUNING
-      UNETK_KNOB(var, "UNETK_PW_VAR", 0);
-      if (dtype == UNETK_BF16 && var == 1) return launch_pw<bf16, MODE, 4, 4, 3>(P, s);      // full lines, 1 WG/CU
-      if (dtype == UNETK_BF16 && var == 2) return launch_pw<bf16, MODE, 8, 4, 3, 1>(P, s);   // full lines, 8 x 32 px
-      if (dtype == UNETK_BF16 && var == 3) return launch_pw<bf16, MODE, 8, 4, 2, 1>(P, s);
+      UNETK_KNOB(var, "UNETK_PW_VAR", 2);
+      if (dtype == UNETK_BF16 && var == 0) return few_k ? launch_pw<bf16, MODE, 4, 2, 3>(P, s) : launch_pw<bf16, MODE>(P, s);
+      if (dtype == UNETK_BF16 && var == 1) return launch_pw<bf16, MODE, 4, 4, 3>(P, s);      // full lines, 4 waves, 1 WG/CU
+      if (dtype == UNETK_BF16 && var == 3) return launch_pw<bf16, MODE, 8, 4, 2, 1>(P, s);   // two buffers
+      if (dtype == UNETK_BF16 && var == 4) return launch_pw<bf16, MODE, 8, 2, 3, 1>(P, s);   // half lines, two 8-wave WGs per CU
+      if (dtype == UNETK_BF16 && var == 5) return few_k ? launch_pw<bf16, MODE, 4, 2>(P, s) : launch_pw<bf16, MODE>(P, s);  // round 2
 #endif
-      if (few_k && nbuf == 3) {
-        if (dtype == UNETK_BF16) return launch_pw<bf16, MODE, 4, 2, 3>(P, s);
-        if (dtype == UNETK_F16) return launch_pw<f16, MODE, 4, 2, 3>(P, s);
-      }
-#ifdef UNETK_TUNING
-      if (dtype == UNETK_BF16) return few_k ? launch_pw<bf16, MODE, 4, 2>(P, s) : launch_pw<bf16, MODE>(P, s);
-      if (dtype == UNETK_F16) return few_k ? launch_pw<f16, MODE, 4, 2>(P, s) : launch_pw<f16, MODE>(P, s);
-#else
-      if (dtype == UNETK_BF16) return launch_pw<bf16, MODE>(P, s);
-      if (dtype == UNETK_F16) return launch_pw<f16, MODE>(P, s);
-#endif
+      if (dtype == UNETK_BF16) return launch_pw<bf16, MODE, 8, 4, 3, 1>(P, s);
+      if (dtype == UNETK_F16) return launch_pw<f16, MODE, 8, 4, 3, 1>(P, s);
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
       return UNETK_ERR_DTYPE;
     }
