@@ -175,6 +175,16 @@ int unetk_conv3x3_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const 
                                   int dx_choff, const void* z_prev, int ldz, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,
                                   int c_out, int dtype, void* stream);
+/* The same fusion for the Up block's ConvTranspose2d (unet_parts.py:53, :65 x1 = self.up(x1)): its input gradient IS the
+ * gradient of the activation of the conv -> BN -> ReLU layer below (the previous block's last layer, unet_parts.py:20-21),
+ * so the dgrad epilogue forms that layer's two BN-backward sums from the value it stores and one read of `z_prev`
+ * [n][h][w][c_in] (pitch ldz) -- `sums` [UNETK_STAT_REPLICAS][c_in][2] doubles zeroed by the caller.  Other shapes /
+ * dtypes run unetk_convT2x2_dgrad followed by unetk_bn_relu_bwd_reduce: same result. */
+int unetk_convT2x2_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype);
+int unetk_convT2x2_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
+                                   const void* z_prev, int ldz, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,
+                                   int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream);
 int unetk_convT2x2_bias_grad_from_sums(const double* sums, int c_total, int c_off, const void* dup, int ld, int n,
                                        int hs, int ws, int c_up, int pad_t, int pad_l, int h_up, int w_up,
                                        double* scratch, float* db, int dtype, void* stream);

@@ -804,8 +804,14 @@ int launch_db(const ConvParams& P, hipStream_t s) {
 // NW / KS: 8 waves and 64-channel chunks (160 KiB: one workgroup per CU), or -- the shallow, HBM-bound levels -- 4 waves
 // and 32-channel chunks (48 KiB): then two or three INDEPENDENT workgroups share a CU and one's epilogue stores run
 // under another's DMA and MFMA phases.  The packed weight stream is the same for both (k-steps in order, NB inner).
-template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2>
+// BNR (MODE 2, MBS == 1, 16-bit types): the written gradient is the gradient of a conv -> BN -> ReLU layer's activation
+// (the Up block's low-res input).  That layer's pre-BatchNorm tensor z at the tile's pixels is fetched two chunks before
+// the tile ends (hidden loads, counted in the loop's own vmcnt arithmetic so that the DMA look-ahead across the tile
+// boundary survives) and the epilogue forms its BN-backward sums from the ROUNDED values it stores: the stand-alone
+// reduction pass (two reads of the tensor) does not run.
+template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2, bool BNR = false>
 __global__ __launch_bounds__(64 * NW, (MBS == 1 && KS == 2 ? 4 : 2)) void pw_db_kernel(ConvParams P) {
+  static_assert(!BNR || (MODE == 2 && MBS == 1 && sizeof(T) == 2 && NBUF >= 3), "BNR: dgrad, one row block, 16-bit");
   constexpr int LA = NBUF - 1;                    // chunks of DMA look-ahead
   constexpr int E = ElemTraits<T>::E;
   constexpr int NB = 4;
@@ -922,8 +928,44 @@ __global__ __launch_bounds__(64 * NW, (MBS == 1 && KS == 2 ? 4 : 2)) void pw_db_
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA * (LA - 1)) : "memory");
   int cur = 0;
 
+  // BNR state: z words of the lane's 16 pixels x 4 adjacent channels, scale/shift of those channels, running sums
+  unsigned long long zq[BNR ? 16 : 1];
+  float bsc[NB], bsh[NB], ts1[NB], ts2[NB];
+  if constexpr (BNR) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zq[i] = 0ull;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      bsc[nb] = P.bn_scale[ch0 + nb];
+      bsh[nb] = P.bn_shift[ch0 + nb];
+      ts1[nb] = ts2[nb] = 0.f;
+    }
+  }
+
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     for (int it = 0; it < niter; ++it) {
+      if constexpr (BNR) {
+        if (it == niter - 2) {
+          // 16 hidden 8-byte loads (in front of this iteration's DMA pieces: the iteration ends on vmcnt(NDMA + 16), the
+          // next one on vmcnt(NDMA), by which the words have landed).  Scalar base + 32-bit lane offset, rows past the
+          // last pixel clamped onto it (masked at use): no per-load 64-bit address lives in registers.
+          const long gb = (long)tile * TP + wid * 32;
+          const long gbc = gb < npix ? gb : npix - 1;
+          const char* zb = reinterpret_cast<const char*>(P.bn_z) + (size_t)gbc * P.ld_bnz * sizeof(T);
+          const long left = npix - 1 - gbc;
+          const int rows_left = left < 31 ? (int)left : 31;
+          const unsigned pitch = (unsigned)P.ld_bnz * (unsigned)sizeof(T);
+          const unsigned lane_off = (unsigned)ch0 * (unsigned)sizeof(T);
+          int h4 = 4 * h;
+          asm volatile("" : "+v"(h4));      // (else the 16 offsets are hoisted out of the tile loop and held in registers)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = min((i & 3) + 8 * (i >> 2) + h4, rows_left);
+            const unsigned voff = (unsigned)row * pitch + lane_off;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(zq[i]) : "v"(voff), "s"(zb) : "memory");
+          }
+        }
+      }
       const char* lds_in = smem + cur * BUF;
       const char* lds_w = lds_in + IN_BYTES;
       // the chunk issued during this one lies LA chunks ahead, possibly in the next tile
@@ -956,8 +998,17 @@ __global__ __launch_bounds__(64 * NW, (MBS == 1 && KS == 2 ? 4 : 2)) void pw_db_
       }
       // the chunk issued LA - 1 iterations ago must have landed; the newest LA - 1 chunks (and nothing older: vmcnt
       // retires in issue order, epilogue stores included) may stay in flight
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA * (LA - 1)) : "memory");
+      if (BNR && it == niter - 2)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA * (LA - 1) + 16) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NDMA * (LA - 1)) : "memory");
       cur = cur + 1 == NBUF ? 0 : cur + 1;
+    }
+    if constexpr (BNR) {
+      // every later use of the z words depends on this statement: nothing that reads them moves above the wait
+      asm volatile("" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]), "+v"(zq[4]), "+v"(zq[5]), "+v"(zq[6]),
+                   "+v"(zq[7]), "+v"(zq[8]), "+v"(zq[9]), "+v"(zq[10]), "+v"(zq[11]), "+v"(zq[12]), "+v"(zq[13]),
+                   "+v"(zq[14]), "+v"(zq[15]));
     }
 
     // ---- epilogue
@@ -1044,28 +1095,79 @@ __global__ __launch_bounds__(64 * NW, (MBS == 1 && KS == 2 ? 4 : 2)) void pw_db_
         }
       } else {
         T* dst0 = reinterpret_cast<T*>(P.y) + P.yoff + (size_t)gb * P.ldy + ch0;
+        int h4 = 4 * h;
+        asm volatile("" : "+v"(h4));        // keeps the 16 row offsets out of the loop-invariant (and spilled) set
+        auto emit = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;       // the whole row block lies inside: no per-row predicate
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (gb + row < npix) {
-            float v[NB];
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + h4;
+            if (FULL || gb + row < npix) {
+              float v[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) v[nb] = acc[mb][nb][i];
-            store_channels<T, NB>(dst0 + row * P.ldy, v);
+              for (int nb = 0; nb < NB; ++nb) v[nb] = acc[mb][nb][i];
+              store_channels<T, NB>(dst0 + row * P.ldy, v);
+              if constexpr (BNR) {
+                const unsigned zw[2] = {(unsigned)zq[i], (unsigned)(zq[i] >> 32)};
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                  const float z = (nb & 1) ? H16<T>::hi(zw[nb >> 1]) : H16<T>::lo(zw[nb >> 1]);
+                  const float f = (float)(T)v[nb];                     // the value stored
+                  const float dz = fmaf(z, bsc[nb], bsh[nb]) > 0.f ? f : 0.f;
+                  ts1[nb] += dz;
+                  ts2[nb] = fmaf(dz, z, ts2[nb]);
+                }
+              }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
           }
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = 0.f;
-        }
+        };
+        if (gb + 32 <= npix) emit(std::true_type{});
+        else emit(std::false_type{});
       }
+    }
+  }
+  if constexpr (BNR) {
+    // lanes l and l ^ 32 hold the same channels; then the 8 waves through LDS (a region of its own behind the buffers:
+    // trailing zero-page DMA may still be landing in them), one fp64 atomic per channel and sum into a replica
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      ts1[nb] += __shfl_xor(ts1[nb], 32, 64);
+      ts2[nb] += __shfl_xor(ts2[nb], 32, 64);
+    }
+    float* part = reinterpret_cast<float*>(smem + NBUF * BUF);          // [NW][BN][2]
+    if (h == 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        part[(wid * BN + NB * j + nb) * 2 + 0] = ts1[nb];
+        part[(wid * BN + NB * j + nb) * 2 + 1] = ts2[nb];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) v += part[w8 * 2 * BN + tid];
+      double vd = (double)v;
+      const int c = nt * BN + (tid >> 1);
+      if (tid & 1) {                                                    // sum dz z -> sum dz (z - mean) invstd
+        float s1 = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) s1 += part[w8 * 2 * BN + tid - 1];
+        vd = (vd - (double)P.bn_mean[c] * (double)s1) * (double)P.bn_invstd[c];
+      }
+      unsafeAtomicAdd(P.stats + ((size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * P.Cout + c) * 2 + (tid & 1), vd);
     }
   }
 }
 
-template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2> int launch_pw(const ConvParams& P, hipStream_t s) {
+template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 2, bool BNR = false>
+int launch_pw(const ConvParams& P, hipStream_t s) {
   constexpr int TP = 32 * MBS * NW;
-  constexpr size_t lds = NBUF * ((size_t)TP * 32 * KS + KS * 4 * 1024);
+  constexpr size_t lds = NBUF * ((size_t)TP * 32 * KS + KS * 4 * 1024) + (BNR ? NW * 128 * 2 * sizeof(float) : 0);
   constexpr int WG_PER_CU = (NW == 8 && !(MBS == 1 && KS == 2)) ? 1 : (160 * 1024) / (int)lds > 2 ? 2 : (160 * 1024) / (int)lds;   // VGPRs: 8 waves per CU
-  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS>), lds);
+  UNETK_ALLOW_LDS((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS, BNR>), lds);
   ConvParams Q = P;
   Q.n_tiles = P.Cout / 128;
   const long npix = (long)P.N * P.H * P.W;
@@ -1095,7 +1197,7 @@ template <typename T, int MODE, int NW = 8, int KS = 4, int NBUF = 2, int MBS = 
   const long nblk = ((ntiles + tpb - 1) / tpb) * Q.n_tiles;
   if (nblk <= 0 || nblk > 0x7ffffff0L) return UNETK_ERR_SHAPE;
   Q.nblk = (int)nblk;
-  hipLaunchKernelGGL((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(64 * NW), lds, s, Q);
+  hipLaunchKernelGGL((pw_db_kernel<T, MODE, NW, KS, NBUF, MBS, BNR>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(64 * NW), lds, s, Q);
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
@@ -1182,6 +1284,13 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
       if (dtype == UNETK_BF16 && var == 4) return launch_pw<bf16, MODE, 8, 2, 3, 1>(P, s);   // half lines, two 8-wave WGs per CU
       if (dtype == UNETK_BF16 && var == 5) return few_k ? launch_pw<bf16, MODE, 4, 2>(P, s) : launch_pw<bf16, MODE>(P, s);  // round 2
 #endif
+      if constexpr (MODE == 2) {
+        if (P.bn_z != nullptr) {      // BN-backward reduction of the layer below in the epilogue (16-bit types)
+          if (dtype == UNETK_BF16) return launch_pw<bf16, MODE, 8, 4, 3, 1, true>(P, s);
+          if (dtype == UNETK_F16) return launch_pw<f16, MODE, 8, 4, 3, 1, true>(P, s);
+          return UNETK_ERR_UNFUSED;
+        }
+      }
       if (dtype == UNETK_BF16) return launch_pw<bf16, MODE, 8, 4, 3, 1>(P, s);
       if (dtype == UNETK_F16) return launch_pw<f16, MODE, 8, 4, 3, 1>(P, s);
       if (dtype == UNETK_F32) return launch_pw<float, MODE>(P, s);
@@ -1189,6 +1298,7 @@ template <int MODE> int dispatch(const ConvParams& P, int dtype, hipStream_t s) 
     }
   }
   if constexpr (MODE != 0) {       // the first-generation kernel serves only the transposed-conv modes
+    if (P.bn_z != nullptr) return UNETK_ERR_UNFUSED;
     if (dtype == UNETK_BF16) return launch<bf16, 2, MODE>(P, s);
     if (dtype == UNETK_F16) return launch<f16, 2, MODE>(P, s);
     if (dtype == UNETK_F32) return launch<float, 2, MODE>(P, s);
@@ -1311,8 +1421,45 @@ int unetk_convT2x2_fwd(const void* x, int ldx, const void* wpk, const float* bia
   return dispatch<1>(P, dtype, (hipStream_t)stream);
 }
 
+namespace {
+int convT_dgrad_common(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int n, int h, int w,
+                       int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream,
+                       const BnReduceArgs* bnr, double* sums);
+}
+
 int unetk_convT2x2_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int n, int h,
                          int w, int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream) {
+  return convT_dgrad_common(dy, lddy, dy_choff, wpk, dx, lddx, n, h, w, c_in, c_out, hs, ws, pad_t, pad_l, dtype, stream,
+                            nullptr, nullptr);
+}
+
+int unetk_convT2x2_dgrad_bn_reduce_is_fused(int c_in, int c_out, int dtype) {
+  // mirrors dispatch<2>: the 16-bit pointwise kernel serves GEMM-N (= c_in) in multiples of 128
+  return unetk_is16(dtype) && c_in > 0 && c_out > 0 && c_out % 64 == 0 && pw_nb(c_in) == 4;
+}
+
+int unetk_convT2x2_dgrad_bn_reduce(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx,
+                                   const void* z_prev, int ldz, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, double* sums, int n, int h, int w, int c_in,
+                                   int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream) {
+  const BnReduceArgs bnr{z_prev, ldz, scale, shift, mean, invstd};
+  const int e = convT_dgrad_common(dy, lddy, dy_choff, wpk, dx, lddx, n, h, w, c_in, c_out, hs, ws, pad_t, pad_l, dtype,
+                                   stream, &bnr, sums);
+  if (e != UNETK_ERR_UNFUSED) return e;
+  // no such epilogue for this shape / dtype: plain dgrad, then the stand-alone reduction pass
+  if (int e2 = convT_dgrad_common(dy, lddy, dy_choff, wpk, dx, lddx, n, h, w, c_in, c_out, hs, ws, pad_t, pad_l, dtype,
+                                  stream, nullptr, nullptr))
+    return e2;
+  return unetk_bn_relu_bwd_reduce(dx, lddx, z_prev, ldz, scale, shift, mean, invstd, sums, (int64_t)n * h * w, c_in,
+                                  dtype, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int convT_dgrad_common(const void* dy, int lddy, int dy_choff, const void* wpk, void* dx, int lddx, int n, int h, int w,
+                       int c_in, int c_out, int hs, int ws, int pad_t, int pad_l, int dtype, void* stream,
+                       const BnReduceArgs* bnr, double* sums) {
   if (n <= 0 || h <= 0 || w <= 0 || !dy || !wpk || !dx) return UNETK_ERR_ARG;
   // GEMM-K per tap = c_out (channels of the up-sampled gradient), GEMM-N = c_in
   if (int e = check_common(dy, lddy, dy_choff, dx, lddx, 0, c_out, c_in, dtype, 128)) return e;
@@ -1320,11 +1467,18 @@ int unetk_convT2x2_dgrad(const void* dy, int lddy, int dy_choff, const void* wpk
   if ((long)hs * ws * lddy >= 0x7fffffffL || (long)h * w * lddx >= 0x7fffffffL) return UNETK_ERR_SHAPE;
   ConvParams P{};
   P.x = dy; P.wpk = wpk; P.y = dx;
+  if (bnr != nullptr) {
+    const int es = unetk_esize(dtype);
+    if (!bnr->z || !bnr->scale || !bnr->shift || !bnr->mean || !bnr->invstd || !sums) return UNETK_ERR_ARG;
+    if (bnr->ldz < c_in) return UNETK_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(bnr->z) & 15) || (bnr->ldz * es) % 16) return UNETK_ERR_ALIGN;
+    P.bn_z = bnr->z; P.ld_bnz = bnr->ldz; P.stats = sums;
+    P.bn_scale = bnr->scale; P.bn_shift = bnr->shift; P.bn_mean = bnr->mean; P.bn_invstd = bnr->invstd;
+  }
   P.N = n; P.H = h; P.W = w; P.Cin = c_out; P.Cout = c_in;
   P.ldx = lddy; P.ldy = lddx; P.xoff = dy_choff; P.yoff = 0;
   P.Hs = hs; P.Ws = ws; P.padT = pad_t; P.padL = pad_l;
   P.tiles_x = host_cdiv(w, 32); P.tiles_y = host_cdiv(h, 8); P.n_tiles = c_in / 64;
   return dispatch<2>(P, dtype, (hipStream_t)stream);
 }
-
-}  // extern "C"
+}  // namespace

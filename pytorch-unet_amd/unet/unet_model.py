@@ -106,6 +106,7 @@ class _UNetImpl:
         if dhead is None:
             done([net.outc.conv.weight, net.outc.conv.bias])
         dcats = [None] * 4
+        sums2 = None
         for k in (3, 2, 1, 0):
             up = ups[k]
             # ConvTranspose2d's bias gradient = channel sums of the concat gradient's second half: accumulated by the
@@ -116,15 +117,20 @@ class _UNetImpl:
             # OutConv's gradients come out of up4's BatchNorm backward (dhead): reported with that layer
             first = [net.outc.conv.weight, net.outc.conv.bias] if (k == 3 and dhead is not None) else None
             dcat = blocks.double_conv_bwd(up.conv, saved['dec'][k], d, grads, True, dhead=dhead if k == 3 else None,
-                                          dx_sums=sums, done=done, done_first=first)
+                                          dx_sums=sums, done=done, done_first=first, sums2=sums2)
             dcats[k] = dcat
-            d = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True, dcat_sums=sums, done=done)
+            # the block's low-res input is the activation of the previous block's (k = 0: down4's) last layer: the
+            # ConvTranspose2d dgrad that writes its gradient also forms that layer's BN-backward sums where it can
+            below = saved['dec'][k - 1][1] if k > 0 else saved['enc'][4][1]          # (x, z, BNState)
+            d, sums2 = blocks.up_bwd(up.up, saved['up'][k], dcat, saved['cats'][k], grads, True, dcat_sums=sums,
+                                     done=done, bn_prev=(below[1], below[2]))
         # encoder, deepest first.  A block's output fed the skip connection and the next block's max-pool: its
         # gradient = first half of dcat + scatter(pool gradient), formed inside the BatchNorm backward kernels
         dpool = None
         for k in (4, 3, 2, 1, 0):
             need_dx = k > 0 or needs[0]
-            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx, dpool=dpool, done=done)
+            d = blocks.double_conv_bwd(enc[k], saved['enc'][k], d, grads, need_dx, dpool=dpool, done=done,
+                                       sums2=sums2 if k == 4 else None)
             dpool = None
             if k > 0:
                 dcat = dcats[4 - k]

@@ -128,6 +128,8 @@ class KernelTimer:
             return 2.0 * a[7] * a[8] * a[9] * 4 * a[10] * a[11]
         if name == 'unetk_convT2x2_dgrad':
             return 2.0 * a[6] * a[7] * a[8] * 4 * a[9] * a[10]
+        if name == 'unetk_convT2x2_dgrad_bn_reduce':
+            return 2.0 * a[13] * a[14] * a[15] * 4 * a[16] * a[17]
         if name == 'unetk_convT2x2_wgrad':
             return 2.0 * a[8] * a[9] * a[10] * 4 * a[11] * a[12]
         return 0.0
@@ -192,6 +194,9 @@ class KernelTimer:
         if name == 'unetk_convT2x2_dgrad':
             n, h, w, ci, co = a[6:11]
             return 'convT_dgrad', (1.0 * n * h * w * (ci + 4 * co) + 4.0 * ci * co) * es(a[15])
+        if name == 'unetk_convT2x2_dgrad_bn_reduce':          # + one read of the layer below's pre-BN tensor
+            n, h, w, ci, co = a[13:18]
+            return 'convT_dgrad', (1.0 * n * h * w * (2 * ci + 4 * co) + 4.0 * ci * co) * es(a[22])
         if name == 'unetk_convT2x2_wgrad':                    # read x and the up-sampled gradient, write fp32 dw
             n, h, w, ci, co = a[8:13]
             return 'convT_wgrad', 1.0 * n * h * w * (ci + 4 * co) * es(a[18]) + 16.0 * ci * co

@@ -297,9 +297,10 @@ def double_conv_fwd(dc, x, dtype, out=None, pool_out=None, head=None):
 
 
 def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhead=None, dx_sums=None, done=None,
-                    done_first=None):
+                    done_first=None, sums2=None):
     """done: per-layer completion callback (see conv_bn_relu_bwd); done_first: parameters that complete together with
-    the block's second layer (OutConv's, when its gradient comes out of this block's BatchNorm backward: `dhead`)."""
+    the block's second layer (OutConv's, when its gradient comes out of this block's BatchNorm backward: `dhead`).
+    sums2: BN-backward sums of the block's SECOND layer, already formed by the kernel that wrote `da2` (up_bwd)."""
     seq = dc.double_conv
     s1, s2 = saved
     c_mid = seq[3].in_channels
@@ -311,9 +312,10 @@ def double_conv_bwd(dc, saved, da2, grads, need_dx, dx_out=None, dpool=None, dhe
     if FUSE_BN_REDUCE and ops.dgrad_bn_reduce_is_fused(c_mid, seq[3].out_channels, s1[1].dtype):
         # s1 = (x, z1, state1): the second conv consumed relu(bn(z1)), so its dgrad epilogue can reduce for BN 1
         da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead,
-                                      bn_prev=(s1[1], s1[2]), done=done2)
+                                      bn_prev=(s1[1], s1[2]), done=done2, bn_sums=sums2)
     else:
-        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead, done=done2), None
+        da1, sums1 = conv_bn_relu_bwd(seq[3], seq[4], s2, da2, grads, True, dpool=dpool, dhead=dhead, done=done2,
+                                      bn_sums=sums2), None
     return conv_bn_relu_bwd(seq[0], seq[1], s1, da1, grads, need_dx, dx_out=dx_out, dx_sums=dx_sums, bn_sums=sums1,
                             done=done)
 
@@ -363,8 +365,15 @@ def up_into_cat(up_mod, x_low, cat, c_skip, dtype):
     return (x_low, h, w, c_low, pad_t, pad_l)
 
 
-def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None, done=None):
-    """dcat_sums: per-channel sums of dcat from the dgrad that wrote it (ConvTranspose2d bias gradient for free)."""
+# fold the BN-backward reduction of the layer below an Up block into the ConvTranspose2d dgrad epilogue
+# (UNETK_FUSE_BN_REDUCE_UP=0: A/B runs)
+FUSE_BN_REDUCE_UP = os.environ.get('UNETK_FUSE_BN_REDUCE_UP', '1') != '0'
+
+
+def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None, done=None, bn_prev=None):
+    """dcat_sums: per-channel sums of dcat from the dgrad that wrote it (ConvTranspose2d bias gradient for free).
+    bn_prev: (z, BNState) of the conv -> BN -> ReLU layer that produced the block's low-res input: where the
+    ConvTranspose2d dgrad kernel can form that layer's BN-backward sums the result is (dx, bn_sums), else (dx, None)."""
     x_low, h, w, c_low, pad_t, pad_l = saved
     ops.run_deferred()                       # parameter groups complete in layout order (unetk.ddp)
     if isinstance(up_mod, torch.nn.ConvTranspose2d):
@@ -374,12 +383,17 @@ def up_bwd(up_mod, saved, dcat, c_skip, grads, need_dx=True, dcat_sums=None, don
         if done is not None:
             done([up_mod.weight, up_mod.bias])
         if not need_dx:
-            return None
-        return ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out, h, w,
-                                  pad_t, pad_l)
+            return None if bn_prev is None else (None, None)
+        if bn_prev is not None and FUSE_BN_REDUCE_UP and ops.convT_dgrad_bn_reduce_is_fused(c_low, c_out, dcat.dtype):
+            return ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out,
+                                      h, w, pad_t, pad_l, bn_prev=bn_prev)
+        dx = ops.convT2x2_dgrad(dcat, c_skip, packed_weight(up_mod, 3, dcat.dtype, c_out, c_low), c_low, c_out, h, w,
+                                pad_t, pad_l)
+        return dx if bn_prev is None else (dx, None)
     if not need_dx:
-        return None
-    return ops.bilinear_bwd(dcat, c_skip, c_low, h, w, pad_t, pad_l)
+        return None if bn_prev is None else (None, None)
+    dx = ops.bilinear_bwd(dcat, c_skip, c_low, h, w, pad_t, pad_l)
+    return dx if bn_prev is None else (dx, None)
 
 
 def up_params(up_block):

@@ -411,10 +411,29 @@ def convT2x2_fwd(x, wpk, bias, cat, choff, c_out, pad_t, pad_l):
                                       stream_ptr()), 'unetk_zero_pad_border')
 
 
-def convT2x2_dgrad(dcat, choff, wpk_d, c_in, c_out, h, w, pad_t, pad_l):
+def convT_dgrad_bn_reduce_is_fused(c_in, c_out, dtype):
+    """Does convT2x2_dgrad(bn_prev=...) fold the reduction into the dgrad kernel (else: two kernels, nothing saved)?"""
+    return bool(fn['unetk_convT2x2_dgrad_bn_reduce_is_fused'](int(c_in), int(c_out), dtype_code(dtype)))
+
+
+def convT2x2_dgrad(dcat, choff, wpk_d, c_in, c_out, h, w, pad_t, pad_l, bn_prev=None):
+    """bn_prev: (z, BNState) of the conv -> BN -> ReLU layer whose activation the transposed convolution consumed: the
+    epilogue also forms that layer's BN-backward sums; returns (dx, bn_sums) then (see conv3x3_dgrad)."""
     require_cuda(dcat, wpk_d)
     n, hs, ws_, ctot, ldd = nhwc_meta(dcat, 'concat gradient')
     dx = new_nhwc(n, h, w, c_in, dcat.dtype, dcat.device)
+    if bn_prev is not None:
+        z, st = bn_prev
+        zn, zh, zw, zc, ldz = nhwc_meta(z, 'producer layer pre-BN tensor')
+        if (zn, zh, zw, zc) != (n, h, w, c_in) or z.dtype != dcat.dtype:
+            raise RuntimeError('convT dgrad: producer layer tensor does not match the input gradient')
+        bn_sums = new_stats(c_in, dcat.device)
+        check(fn['unetk_convT2x2_dgrad_bn_reduce'](dcat.data_ptr(), ldd, choff, wpk_d.data_ptr(), dx.data_ptr(), c_in,
+                                                   z.data_ptr(), ldz, st.scale.data_ptr(), st.shift.data_ptr(),
+                                                   st.mean.data_ptr(), st.invstd.data_ptr(), bn_sums.data_ptr(), n, h, w,
+                                                   c_in, c_out, hs, ws_, pad_t, pad_l, dtype_code(dcat.dtype),
+                                                   stream_ptr()), 'unetk_convT2x2_dgrad_bn_reduce')
+        return dx, bn_sums
     check(fn['unetk_convT2x2_dgrad'](dcat.data_ptr(), ldd, choff, wpk_d.data_ptr(), dx.data_ptr(), c_in, n, h, w, c_in,
                                      c_out, hs, ws_, pad_t, pad_l, dtype_code(dcat.dtype), stream_ptr()),
           'unetk_convT2x2_dgrad')

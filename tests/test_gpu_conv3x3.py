@@ -173,3 +173,80 @@ def test_double_conv_backward_same_with_and_without_fused_bn_reduce(cin, cmid):
     assert float((dx0.float() - dx1.float()).abs().max()) <= 1e-2 * float(dx0.float().abs().max())
     for p in g0:
         assert float((g0[p] - g1[p]).abs().max()) <= 2e-3 * float(g0[p].abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('dtype', ALL)
+@pytest.mark.parametrize('n,h,w,cin,hs,ws', [
+    (1, 8, 32, 128, 16, 64),      # exactly one 256-pixel tile
+    (2, 13, 21, 128, 27, 43),     # ragged last tile, odd skip size (F.pad offsets), GEMM-K = 4 * 64
+    (1, 20, 40, 256, 40, 80),     # two n-tiles, several tiles per workgroup
+    (3, 5, 7, 512, 10, 14),       # less than one tile in all; four n-tiles
+    (2, 6, 5, 64, 12, 10),        # GEMM-N not a multiple of 128: no fused kernel, the two-kernel path of the same call
+])
+def test_convT_dgrad_with_bn_reduce_of_the_layer_below(dtype, n, h, w, cin, hs, ws):
+    """unetk_convT2x2_dgrad_bn_reduce == unetk_convT2x2_dgrad followed by unetk_bn_relu_bwd_reduce: the gradient bit
+    for bit, the two per-channel sums to fp32 summation-order accuracy and against fp64."""
+    from unetk import ops
+    from unetk._native import fn, check, dtype_code, stream_ptr
+    cout = 64 if cin == 64 else cin // 2
+    pt, pl = (hs - 2 * h) // 2, (ws - 2 * w) // 2
+    dcat = _rand((n, hs, ws, cin), 31).to(dtype).cuda()                  # [skip | up] gradient, up half = channels cout..
+    wq = _rand((cin, cout, 2, 2), 32, 0.05).to(dtype).float()
+    wpk = ops.pack_weight(3, wq.cuda(), cout, cin, dtype)
+    z = _rand((n, h, w, cin), 33, 2.0).to(dtype).cuda()
+    st = _State(cin, 34)
+    assert ops.convT_dgrad_bn_reduce_is_fused(cin, cout, dtype) == (dtype != torch.float32 and cin % 128 == 0)
+    ref_dx = ops.convT2x2_dgrad(dcat, cin - cout, wpk, cin, cout, h, w, pt, pl)
+    ref_sums = ops.new_stats(cin, 'cuda')
+    check(fn['unetk_bn_relu_bwd_reduce'](ref_dx.data_ptr(), cin, z.data_ptr(), cin, st.scale.data_ptr(),
+                                         st.shift.data_ptr(), st.mean.data_ptr(), st.invstd.data_ptr(),
+                                         ref_sums.data_ptr(), n * h * w, cin, dtype_code(dtype), stream_ptr()), 'reduce')
+    dx, sums = ops.convT2x2_dgrad(dcat, cin - cout, wpk, cin, cout, h, w, pt, pl, bn_prev=(z, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, ref_dx)
+    a, b = sums.sum(0).cpu().numpy(), ref_sums.sum(0).cpu().numpy()
+    d = ref_dx.double().reshape(-1, cin)
+    zz = z.double().reshape(-1, cin)
+    m = (zz * st.scale.double() + st.shift.double() > 0)
+    mag1 = (d.abs() * m).sum(0).cpu().numpy()
+    mag2 = ((d * (zz - st.mean.double()) * st.invstd.double()).abs() * m).sum(0).cpu().numpy()
+    assert np.all(np.abs(a[:, 0] - b[:, 0]) <= 2e-5 * mag1 + 1e-6)
+    assert np.all(np.abs(a[:, 1] - b[:, 1]) <= 2e-5 * mag2 + 1e-6)
+    assert mag1.min() > 0 and np.abs(b).max() > 0
+    e1 = (d * m).sum(0).cpu().numpy()
+    e2 = (d * m * (zz - st.mean.double()) * st.invstd.double()).sum(0).cpu().numpy()
+    assert np.all(np.abs(a[:, 0] - e1) <= 2e-5 * mag1 + 1e-6)
+    assert np.all(np.abs(a[:, 1] - e2) <= 2e-5 * mag2 + 1e-6)
+
+
+def test_whole_net_backward_same_with_and_without_the_convT_bn_reduce():
+    """UNet(3, 2) bf16 train-mode backward with blocks.FUSE_BN_REDUCE_UP on/off: same loss, parameter gradients to
+    summation order (the fused epilogue replaces four stand-alone reduction passes)."""
+    from unetk import blocks
+    from unet import UNet
+    torch.manual_seed(5)
+    net = UNet(3, 2, False).cuda().to(memory_format=torch.channels_last).train()
+    x = _rand((2, 3, 48, 80), 41).cuda().contiguous(memory_format=torch.channels_last)
+    target = (torch.rand((2, 48, 80), generator=torch.Generator().manual_seed(42)) < 0.3).long().cuda()
+    outs = []
+    before = blocks.FUSE_BN_REDUCE_UP
+    for fuse in (False, True):
+        blocks.FUSE_BN_REDUCE_UP = fuse
+        try:
+            net.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = torch.nn.functional.cross_entropy(net(x).float(), target)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}))
+        finally:
+            blocks.FUSE_BN_REDUCE_UP = before
+    (l0, g0), (l1, g1) = outs
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    # the sums differ in fp32 summation order -> last-bit differences of the BN-backward coefficients -> single bf16
+    # roundings of the gradients below them: L2-relative (1 ulp of bf16 is 4e-3..8e-3 of an element)
+    # (bias gradients are sums with heavy cancellation over the few pixels of this small image: 0.9 % measured)
+    worst = max((float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
+    assert worst[0] <= 2e-2, worst
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 3e-2 * float(g0[k].abs().max()) + 1e-7, k
