@@ -1181,7 +1181,8 @@ int unetk_bn_relu_bwd_reduce(const void* dout, int lddo, const void* y, int ldy,
   if (256 % pg) return UNETK_ERR_SHAPE;   // channel counts are multiples of 64: pg is a power of two
   const int lanes = 256 / pg;
   long gx = (npix + lanes - 1) / lanes;
-  if (gx > 1024) gx = 1024;
+  UNETK_KNOB(gcap, "UNETK_BNR_GRID", 1024);
+  if (gx > gcap) gx = gcap;
   dim3 grid((unsigned)gx, (unsigned)((ppp + 255) / 256));
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dout, lddo, (const T*)y, ldy, scale, shift, mean, invstd, sums,

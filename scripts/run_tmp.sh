@@ -1,2 +1,6 @@
 set -e
-timeout -k 10 300 python -u -m pytest tests/test_gpu_conv3x3.py -m gpu -x -q --timeout 120 --timeout-method thread -k "whole_net" 2>&1 | grep -v "^E   *+" | tail -25
+export UNETK_LIB=exp/libunetk_pw3.so
+for g in 1024 512 256 2048 1024; do
+  echo "== GRID=$g"
+  UNETK_BNR_GRID=$g timeout -k 10 120 python scripts/perf_bn.py 2>&1 | grep -v "amdgpu.ids" | sed 's/apply [0-9.]* ms [0-9.]* TB.s | //; s/| bwd_apply.*//'
+done
