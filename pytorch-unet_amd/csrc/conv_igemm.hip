@@ -794,16 +794,17 @@ int launch_db(const ConvParams& P, hipStream_t s) {
 // ConvTranspose2d k2 s2 forward (MODE 1) and dgrad (MODE 2), second generation: the same double-buffered hidden
 // LDS-DMA pipeline as conv3x3_db_kernel, for the pointwise GEMMs.
 //
-//   tile   512 CONSECUTIVE pixels of the flattened low-res grid (no 2-D tile, no ragged-edge waste) x 128 channels;
-//          8 waves, wave w owns pixels 64w .. 64w+63 (two 32-pixel MFMA row blocks) x 4 column blocks
-//   LDS    2 x { 512 pixels x 128 B (64 bf16 / 32 fp32 channels)  +  4 k-steps x 4 weight fragments } = 160 KiB
-//   loop   chunk = (tap,) 64 channels: 4 k-steps x 8 MFMAs per wave; the 10 DMA pieces per wave of the next chunk go
-//          out 3,3,3,1 between the k-steps; one barrier per chunk
+//   tile   TP = 32 * MBS * NW CONSECUTIVE pixels of the flattened low-res grid (no 2-D tile, no ragged-edge waste) x 128
+//          channels; wave w owns pixels 32*MBS*w .. (MBS 32-pixel MFMA row blocks) x 4 column blocks
+//   LDS    NBUF x { TP pixels x 32*KS B (16*KS bf16 / 8*KS fp32 channels)  +  KS k-steps x 4 weight fragments }
+//   loop   chunk = (tap,) 16*KS channels: KS k-steps x 4*MBS MFMAs per wave; the DMA pieces of the chunk NBUF - 1 ahead go
+//          out between the k-steps; one barrier per chunk, behind `vmcnt(pieces of the NBUF - 2 newest chunks)`
 //   MODE 1 epilogue: + bias, pixel-shuffle store (tap = channel / Co) into the concat buffer at a channel offset
 //   MODE 2 operand:  per tap the stride-2 gather of the up-sampled gradient (per-lane DMA source addresses)
-// NW / KS: 8 waves and 64-channel chunks (160 KiB: one workgroup per CU), or -- the shallow, HBM-bound levels -- 4 waves
-// and 32-channel chunks (48 KiB): then two or three INDEPENDENT workgroups share a CU and one's epilogue stores run
-// under another's DMA and MFMA phases.  The packed weight stream is the same for both (k-steps in order, NB inner).
+// Forms: fp32 -- 8 waves x 2 row blocks, 32-channel (128-byte) chunks, two 80-KiB buffers (round 2);
+// 16-bit types -- 8 waves x 1 row block (256-pixel tiles), 64-channel chunks = whole 128-byte lines per DMA piece, three
+// 48-KiB buffers with two chunks of look-ahead (round 3).  The 4-wave / 32-channel forms of round 2 (two workgroups per
+// CU) are compiled only into -DUNETK_TUNING builds.  The packed weight stream is the same for all (k-steps in order).
 // BNR (MODE 2, MBS == 1, 16-bit types): the written gradient is the gradient of a conv -> BN -> ReLU layer's activation
 // (the Up block's low-res input).  That layer's pre-BatchNorm tensor z at the tile's pixels is fetched two chunks before
 // the tile ends (hidden loads, counted in the loop's own vmcnt arithmetic so that the DMA look-ahead across the tile
