@@ -19,6 +19,9 @@ Rank 0 prints ONE JSON line with the whole-job images/sec plus
   cpu_baseline -- the reference's PyTorch CPU path (oracle/unet_torch.py, a stock-torch.nn restatement) timed on
                   the box's host cores on a bounded sample (batch 1), kind "port" (N = 1, default config only): the
                   train step, and beside it BASELINE.json configs[0] (fp32 eval forward, N = 1).
+  other_configs -- (default command only) BASELINE.json configs[2..4] run through this same harness afterwards, one child
+                  process each (5 steps, 2 warm-up): value, ms/step and the roofline fraction of each; context beside
+                  the headline value, skipped with --no-other-configs or --no-cpu-baseline (the quick forms)
 --force-collectives: run the gradient buckets through a 1-rank RCCL group (what one GPU can say about the
 data-parallel path: launch + stream hand-over + CU contention of RCCL's kernels against the whole-CU conv kernels).
 
@@ -77,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument('--config', choices=sorted(CONFIGS), default='train959')
     ap.add_argument('--batch-size', '-b', type=int, default=None, help='images per GPU (weak scaling); default per config')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='default line only: do not run BASELINE.json configs[2..4] as child processes afterwards')
     ap.add_argument('--height', type=int, default=None, help='sanity runs at other sizes; the metric is quoted at the config size')
     ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
@@ -117,6 +122,35 @@ def launch_ranks(args, argv):
         sys.stderr.write('bench.py: the ranks exited cleanly but printed no result line\n')
         rc = 1
     return rc
+
+
+def other_configs(steps=5, warmup=2, limit_s=150):
+    """BASELINE.json configs[2..4] through this same harness, one fresh child process each (sequentially, after the
+    headline measurement; this process is idle meanwhile), so that the driver's record of the default command carries
+    them too.  Context beside the headline value, never part of it; a child that fails or overruns leaves an error
+    entry instead of a number."""
+    res = {}
+    for name in ('infer959_bilinear', 'train1918', 'train512_c21'):
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', str(steps), '--warmup', str(warmup),
+               '--no-cpu-baseline', '--no-other-configs']
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=limit_s)
+            line = next((l for l in reversed(p.stdout.splitlines()) if l.startswith('{') and '"metric"' in l), None)
+            if p.returncode != 0 or line is None:
+                res[name] = {'error': f'exit code {p.returncode}, no result line' if line is None else f'exit code {p.returncode}'}
+                continue
+            d = json.loads(line)
+            r = d.get('roofline') or {}
+            res[name] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                         'steps': d['steps'], 'warmup': d['warmup'], 'dtype': d['dtype'], 'workload': d['config']['workload'],
+                         'global_batch': d['config']['global_batch'], 'model_tflops': d['model_tflops'],
+                         'roofline': {k: r.get(k) for k in ('kernel', 'launches_per_step', 'avg_launch_ms', 'achieved', 'peak',
+                                                            'unit', 'frac')},
+                         'wall_s': round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            res[name] = {'error': f'no result within {limit_s} s'}
+    return res
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -405,6 +439,10 @@ def main(argv=None):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'train959':
         cpu = cpu_baseline()
+    others = None
+    if rank == 0 and world == 1 and not (args.no_other_configs or args.no_cpu_baseline) and args.config == 'train959' and not args.force_collectives \
+            and (hh, ww) == (cfg['h'], cfg['w']) and args.amp_dtype == 'bf16' and args.batch_size is None:
+        others = other_configs()
 
     if rank == 0:
         ips = world * B * args.steps / elapsed
@@ -422,6 +460,8 @@ def main(argv=None):
             'model_tflops': ips * cfg['gflop'] * (hh * ww) / (cfg['h'] * cfg['w']) / 1e3, 'final_loss': loss_val,
             'roofline': roofline, 'roofline_hbm': roofline_hbm, 'cpu_baseline': cpu,
         }
+        if others is not None:
+            out['other_configs'] = others
         if args.force_collectives:
             out['force_collectives'] = {'backend': 'nccl', 'world': world,
                                         'collectives_per_step': len(trainer.sync.launched) if cfg['train'] else 0,
