@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
 #pragma unroll
   for (int i = 0; i < E; ++i) s1[i] = s2[i] = 0.f;
   if (active) {
-    float sc[E], sh[E], mu[E], is[E];
+    // the second sum runs as sum dz*y and becomes sum dz*(y - mean)*invstd once per thread at the end (one multiply-add
+    // per element instead of three, as in the dgrad-fused reductions; a thread's share is at most a few thousand pixels)
+    float sc[E], sh[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-      sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
-    }
+    for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; }
     for (long pix = (long)blockIdx.x * lanes + plane; pix < npix; pix += (long)gridDim.x * lanes) {
       float g[E], v[E];
       Vec<T>::load(dout + pix * lddo + c0, g);
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
       for (int i = 0; i < E; ++i) {
         const float dz = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
         s1[i] += dz;
-        s2[i] += dz * (v[i] - mu[i]) * is[i];
+        s2[i] = fmaf(dz, v[i], s2[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       atomicAdd(&red[(piece_in_group * E + i) * 2 + 0], s1[i]);
-      atomicAdd(&red[(piece_in_group * E + i) * 2 + 1], s2[i]);
+      atomicAdd(&red[(piece_in_group * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
     }
   }
   __syncthreads();
@@ -387,6 +387,19 @@ template <typename T> __device__ __forceinline__ uint4 raw_load(const T* p) {
   return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
 }
 
+// relu(bn(.)) of two values, rounded to T as the forward stored them: one packed conversion per pair
+template <typename T>
+__device__ __forceinline__ void act_pair(float p0, float p1, float& a0, float& a1) {
+  if constexpr (sizeof(T) == 2) {
+    const unsigned r = pack2<T>(fmaxf(p0, 0.f), fmaxf(p1, 0.f));
+    a0 = H16<T>::lo(r);
+    a1 = H16<T>::hi(r);
+  } else {
+    a0 = fmaxf(p0, 0.f);
+    a1 = fmaxf(p1, 0.f);
+  }
+}
+
 template <typename T>
 struct QuadGrad {
   static constexpr int E = Vec<T>::E;
@@ -415,12 +428,13 @@ struct QuadGrad {
     for (int k = 0; k < 4; ++k) { yv[k] = raw_elem<T>(v[k], i); gv[k] = raw_elem<T>(g[k], i); }
     if (hx && hy) {       // complete window (floor mode drops an odd last row / column)
       int a = 0;
-      float m = to_f32(from_f32<T>(fmaxf(fmaf(yv[0], sc, sh), 0.f)));
+      float act[4];
+      act_pair<T>(fmaf(yv[0], sc, sh), fmaf(yv[1], sc, sh), act[0], act[1]);
+      act_pair<T>(fmaf(yv[2], sc, sh), fmaf(yv[3], sc, sh), act[2], act[3]);
+      float m = act[0];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        const float ak = to_f32(from_f32<T>(fmaxf(fmaf(yv[k], sc, sh), 0.f)));
-        if (ak > m) { m = ak; a = k; }
-      }
+      for (int k = 1; k < 4; ++k)
+        if (act[k] > m) { m = act[k]; a = k; }
       const float gpi = raw_elem<T>(gp, i);
 #pragma unroll
       for (int k = 0; k < 4; ++k) gv[k] += (a == k) ? gpi : 0.f;
@@ -441,10 +455,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
   const int c0 = piece * E;
   for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
   __syncthreads();
-  float sc[E], sh[E], mu[E], is[E], s1[E], s2[E];
+  float sc[E], sh[E], s1[E], s2[E];          // s2: sum dz*y, corrected to sum dz*(y - mean)*invstd at the end (see above)
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i];
     s1[i] = s2[i] = 0.f;
   }
   const int QH = (H + 1) / 2, QW = (W + 1) / 2;
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
       for (int k = 0; k < 4; ++k) {
         const float dz = (Q.has(k) && fmaf(yv[k], sc[i], sh[i]) > 0.f) ? gv[k] : 0.f;
         s1[i] += dz;
-        s2[i] += dz * (yv[k] - mu[i]) * is[i];
+        s2[i] = fmaf(dz, yv[k], s2[i]);
       }
       __builtin_amdgcn_sched_barrier(0);     // one channel element at a time
     }
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
-    atomicAdd(&red[(piece * E + i) * 2 + 1], s2[i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
   }
   __syncthreads();
   double* dst = sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C * 2;
@@ -574,11 +588,16 @@ struct HeadQuad {
   }
 };
 
+// the value another lane of the row holds, through the DPP path of the VALU (no LDS round trip); every lane active
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // Forward of the same pair (unet_parts.py:20-21 then :74): BatchNorm + ReLU apply of the last block's last layer that
 // also emits OutConv's logits -- the activation is in registers, so the 1x1 convolution costs n_classes dot products
 // per pixel (8 channels per lane, then an xor-shuffle sum over the pixel's lanes: the arithmetic of
 // conv1x1_fwd_kernel on the rounded activation) and no pass over the activation.
-template <typename T, int NCLS>
+template <typename T, int NCLS, bool STORE>
 __global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __restrict__ y, int ldy,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, T* __restrict__ out,
@@ -619,21 +638,38 @@ __global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __rest
       const uint4 raw = raws[u];
       float a[E];
 #pragma unroll
-      for (int i = 0; i < E; ++i) a[i] = fmaxf(fmaf(raw_elem<T>(raw, i), sc[i], sh[i]), 0.f);
-      if (live && out != nullptr) Vec<T>::store(out + p * ldo + c0, a);
+      for (int i = 0; i < E; i += 2)    // a[] = the activation as stored (rounded to T): what OutConv reads
+        act_pair<T>(fmaf(raw_elem<T>(raw, i), sc[i], sh[i]), fmaf(raw_elem<T>(raw, i + 1), sc[i + 1], sh[i + 1]), a[i], a[i + 1]);
+      if (STORE && live) Vec<T>::store(out + p * ldo + c0, a);
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) {
         float d = 0.f;
 #pragma unroll
-        for (int i = 0; i < E; ++i) d = fmaf(to_f32(from_f32<T>(a[i])), wk[k][i], d);
+        for (int i = 0; i < E; ++i) d = fmaf(a[i], wk[k][i], d);
         acc[u][k] = d;
       }
     }
-    for (int o = ppp >> 1; o > 0; o >>= 1)
+    if (ppp == 8) {
+      // a pixel = one aligned group of 8 lanes (64 channels in 16-bit elements: the U-Net's last layer): the sum runs
+      // on DPP operands of the adds -- lane ^ 1, lane ^ 2 inside a quad, then the mirrored half row, which pairs the
+      // two quads -- instead of 3 x 4 x NCLS ds_bpermute round trips through the LDS pipeline per trip
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int k = 0; k < NCLS; ++k) acc[u][k] += __shfl_xor(acc[u][k], o, 64);
+        for (int k = 0; k < NCLS; ++k) {
+          float v = acc[u][k];
+          v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+          v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+          v += dpp_f32<0x141>(v);       // row_half_mirror
+          acc[u][k] = v;
+        }
+    } else {
+      for (int o = ppp >> 1; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < NCLS; ++k) acc[u][k] += __shfl_xor(acc[u][k], o, 64);
+    }
     if (piece == 0 && p0 < npix) {
       if (vec_ok && p0 + 3 < npix) {
         alignas(16) T tmp[((4 * NCLS + PER - 1) / PER) * PER];
@@ -670,14 +706,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
   for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
   for (int i = threadIdx.x; i < NCLS * (C + 1); i += 256) hred[i] = 0.f;
   __syncthreads();
-  float sc[E], sh[E], mu[E], is[E], s1[E], s2[E], wk[NCLS][E];
+  // The second sum runs as sum dz*y and becomes sum dz*(y - mean)*invstd once per thread at the end (one multiply-add
+  // per element instead of three, as in the dgrad-fused reductions); a thread's share is a few hundred pixels.
+  float sc[E], sh[E], s1[E], s2[E], wk[NCLS][E];
   // head_sums != NULL: OutConv's weight / bias gradient as a by-product -- its input IS this layer's activation
   // relu(bn(y)) (rounded to T as the forward stored it), which this pass recomputes for the mask anyway:
   //   dw[k][c] = sum_p dl[p][k] * a[p][c],  db[k] = sum_p dl[p][k]           (no pass over the activation)
   float hw[NCLS][E], hb[NCLS];
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i];
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i];
     s1[i] = s2[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) { wk[k][i] = w[k * C + c0 + i]; hw[k][i] = 0.f; }
@@ -697,26 +735,31 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
         hb[k] += Q.gk[u][k];
       }
 #pragma unroll
-      for (int i = 0; i < E; ++i) {
-        const float v = raw_elem<T>(Q.yraw[u], i);
-        const float pre = fmaf(v, sc[i], sh[i]);
-        const float a = to_f32(from_f32<T>(fmaxf(pre, 0.f)));
-        float g = 0.f;
+      for (int i = 0; i < E; i += 2) {
+        const float v0 = raw_elem<T>(Q.yraw[u], i), v1 = raw_elem<T>(Q.yraw[u], i + 1);
+        const float pre0 = fmaf(v0, sc[i], sh[i]), pre1 = fmaf(v1, sc[i + 1], sh[i + 1]);
+        float a0, a1;
+        act_pair<T>(pre0, pre1, a0, a1);
+        float g0 = 0.f, g1 = 0.f;
 #pragma unroll
         for (int k = 0; k < NCLS; ++k) {
-          g = fmaf(Q.gk[u][k], wk[k][i], g);
-          hw[k][i] = fmaf(Q.gk[u][k], a, hw[k][i]);
+          g0 = fmaf(Q.gk[u][k], wk[k][i], g0);
+          g1 = fmaf(Q.gk[u][k], wk[k][i + 1], g1);
+          hw[k][i] = fmaf(Q.gk[u][k], a0, hw[k][i]);
+          hw[k][i + 1] = fmaf(Q.gk[u][k], a1, hw[k][i + 1]);
         }
-        const float dz = pre > 0.f ? g : 0.f;
-        s1[i] += dz;
-        s2[i] += dz * (v - mu[i]) * is[i];
+        const float dz0 = pre0 > 0.f ? g0 : 0.f, dz1 = pre1 > 0.f ? g1 : 0.f;
+        s1[i] += dz0;
+        s1[i + 1] += dz1;
+        s2[i] = fmaf(dz0, v0, s2[i]);
+        s2[i + 1] = fmaf(dz1, v1, s2[i + 1]);
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
-    atomicAdd(&red[(piece * E + i) * 2 + 1], s2[i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
   }
   if (head_sums != nullptr) {
 #pragma unroll
@@ -1233,10 +1276,13 @@ int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const f
   // a pixel's lanes must share a wave for the shuffle sum: ppp a power of two <= 64
   if (n_classes < 1 || n_classes > kHeadMax || ldl < n_classes || ppp > 64 || (ppp & (ppp - 1))) return UNETK_ERR_SHAPE;
   const int grid = ew_grid((npix + 3) / 4, 256 / ppp, 256 * EW_APPLY_MUL);
-#define HEAD_FWD(NC)                                                                                                \
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_apply_head_kernel<T, NC>), dim3(grid), dim3(256), 0,                 \
+  // STORE: the activation itself is wanted too (out != NULL); the training forward of the whole net passes NULL
+#define HEAD_FWD_S(NC, ST)                                                                                          \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_apply_head_kernel<T, NC, ST>), dim3(grid), dim3(256), 0,             \
                                        (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, w, bias,   \
                                        (T*)logits, ldl, (long)npix, c))
+#define HEAD_FWD(NC)                                                                                                \
+  if (out != nullptr) { HEAD_FWD_S(NC, true); } else { HEAD_FWD_S(NC, false); }
   switch (n_classes) {
     case 1: HEAD_FWD(1); break;
     case 2: HEAD_FWD(2); break;
@@ -1244,6 +1290,7 @@ int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const f
     default: HEAD_FWD(4); break;
   }
 #undef HEAD_FWD
+#undef HEAD_FWD_S
   UNETK_CHECK_LAUNCH();
   return UNETK_OK;
 }
