@@ -218,6 +218,19 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
   }
 }
 
+// Second sum of the BatchNorm-backward reduction, S2 = sum dz * (y - mean) * invstd.  16-bit tensors accumulate sum dz*y
+// and are corrected once per thread (one multiply-add per element; the 8-11 bit mantissa of the stored y bounds
+// |mean| / std, so the correction cancels nothing the rounding of y has not lost already -- the dgrad-fused reductions
+// do the same); fp32 tensors keep the centred operand and only move the multiplication by invstd to the end.
+template <typename T> __device__ __forceinline__ float s2_step(float s2, float dz, float v, float mu) {
+  if constexpr (sizeof(T) == 2) return fmaf(dz, v, s2);
+  else return fmaf(dz, v - mu, s2);
+}
+template <typename T> __device__ __forceinline__ float s2_final(float s1, float s2, float mu, float is) {
+  if constexpr (sizeof(T) == 2) return fmaf(-mu, s1, s2) * is;
+  else return s2 * is;
+}
+
 // ------------------------------------------------------------------------------------------ BN + ReLU backward
 // pass 1: per-channel  S1 = sum dz,  S2 = sum dz*xhat   with dz = dout * [bn(y) > 0], xhat = (y-mean)*invstd
 template <typename T>
@@ -244,11 +257,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
 #pragma unroll
   for (int i = 0; i < E; ++i) s1[i] = s2[i] = 0.f;
   if (active) {
-    // the second sum runs as sum dz*y and becomes sum dz*(y - mean)*invstd once per thread at the end (one multiply-add
-    // per element instead of three, as in the dgrad-fused reductions; a thread's share is at most a few thousand pixels)
-    float sc[E], sh[E];
+    float sc[E], sh[E], mu[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; }
+    for (int i = 0; i < E; ++i) { sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i]; }
     for (long pix = (long)blockIdx.x * lanes + plane; pix < npix; pix += (long)gridDim.x * lanes) {
       float g[E], v[E];
       Vec<T>::load(dout + pix * lddo + c0, g);
@@ -257,13 +268,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
       for (int i = 0; i < E; ++i) {
         const float dz = fmaf(v[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
         s1[i] += dz;
-        s2[i] = fmaf(dz, v[i], s2[i]);
+        s2[i] = s2_step<T>(s2[i], dz, v[i], mu[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       atomicAdd(&red[(piece_in_group * E + i) * 2 + 0], s1[i]);
-      atomicAdd(&red[(piece_in_group * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
+      atomicAdd(&red[(piece_in_group * E + i) * 2 + 1], s2_final<T>(s1[i], s2[i], mu[i], invstd[c0 + i]));
     }
   }
   __syncthreads();
@@ -455,10 +466,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
   const int c0 = piece * E;
   for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
   __syncthreads();
-  float sc[E], sh[E], s1[E], s2[E];          // s2: sum dz*y, corrected to sum dz*(y - mean)*invstd at the end (see above)
+  float sc[E], sh[E], mu[E], s1[E], s2[E];   // (mu: only the fp32 form reads it inside the loop, see s2_step)
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i];
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i];
     s1[i] = s2[i] = 0.f;
   }
   const int QH = (H + 1) / 2, QW = (W + 1) / 2;
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
       for (int k = 0; k < 4; ++k) {
         const float dz = (Q.has(k) && fmaf(yv[k], sc[i], sh[i]) > 0.f) ? gv[k] : 0.f;
         s1[i] += dz;
-        s2[i] = fmaf(dz, yv[k], s2[i]);
+        s2[i] = s2_step<T>(s2[i], dz, yv[k], mu[i]);
       }
       __builtin_amdgcn_sched_barrier(0);     // one channel element at a time
     }
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
-    atomicAdd(&red[(piece * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], s2_final<T>(s1[i], s2[i], mean[c0 + i], invstd[c0 + i]));
   }
   __syncthreads();
   double* dst = sums + (size_t)(blockIdx.x & (UNETK_STAT_REPLICAS - 1)) * C * 2;
@@ -706,16 +717,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
   for (int i = threadIdx.x; i < ppp * E * 2; i += 256) red[i] = 0.f;
   for (int i = threadIdx.x; i < NCLS * (C + 1); i += 256) hred[i] = 0.f;
   __syncthreads();
-  // The second sum runs as sum dz*y and becomes sum dz*(y - mean)*invstd once per thread at the end (one multiply-add
-  // per element instead of three, as in the dgrad-fused reductions); a thread's share is a few hundred pixels.
-  float sc[E], sh[E], s1[E], s2[E], wk[NCLS][E];
+  float sc[E], sh[E], mu[E], s1[E], s2[E], wk[NCLS][E];      // (mu: see s2_step)
   // head_sums != NULL: OutConv's weight / bias gradient as a by-product -- its input IS this layer's activation
   // relu(bn(y)) (rounded to T as the forward stored it), which this pass recomputes for the mask anyway:
   //   dw[k][c] = sum_p dl[p][k] * a[p][c],  db[k] = sum_p dl[p][k]           (no pass over the activation)
   float hw[NCLS][E], hb[NCLS];
 #pragma unroll
   for (int i = 0; i < E; ++i) {
-    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i];
+    sc[i] = scale[c0 + i]; sh[i] = shift[c0 + i]; mu[i] = mean[c0 + i];
     s1[i] = s2[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) { wk[k][i] = w[k * C + c0 + i]; hw[k][i] = 0.f; }
@@ -751,15 +760,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_head_kernel(
         const float dz0 = pre0 > 0.f ? g0 : 0.f, dz1 = pre1 > 0.f ? g1 : 0.f;
         s1[i] += dz0;
         s1[i + 1] += dz1;
-        s2[i] = fmaf(dz0, v0, s2[i]);
-        s2[i + 1] = fmaf(dz1, v1, s2[i + 1]);
+        s2[i] = s2_step<T>(s2[i], dz0, v0, mu[i]);
+        s2[i + 1] = s2_step<T>(s2[i + 1], dz1, v1, mu[i + 1]);
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     atomicAdd(&red[(piece * E + i) * 2 + 0], s1[i]);
-    atomicAdd(&red[(piece * E + i) * 2 + 1], fmaf(-mean[c0 + i], s1[i], s2[i]) * invstd[c0 + i]);
+    atomicAdd(&red[(piece * E + i) * 2 + 1], s2_final<T>(s1[i], s2[i], mean[c0 + i], invstd[c0 + i]));
   }
   if (head_sums != nullptr) {
 #pragma unroll
