@@ -663,7 +663,9 @@ __global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __rest
     if (ppp == 8) {
       // a pixel = one aligned group of 8 lanes (64 channels in 16-bit elements: the U-Net's last layer): the sum runs
       // on DPP operands of the adds -- lane ^ 1, lane ^ 2 inside a quad, then the mirrored half row, which pairs the
-      // two quads -- instead of 3 x 4 x NCLS ds_bpermute round trips through the LDS pipeline per trip
+      // two quads (after the first two steps the four lanes of a quad hold the same value, so this equals lane ^ 4 bit
+      // for bit: the ascending xor order of the generic loop below and of conv1x1_fwd) -- instead of 3 x 4 x NCLS
+      // ds_bpermute round trips through the LDS pipeline per trip
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_head_kernel(const T* __rest
           acc[u][k] = v;
         }
     } else {
-      for (int o = ppp >> 1; o > 0; o >>= 1)
+      for (int o = 1; o < ppp; o <<= 1)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
           for (int i = 0; i < E; ++i) a = fmaf(v[u][i], wr[k][i], a);
           acc[u][k] = a;
         }
-      for (int o = G >> 1; o > 0; o >>= 1)
+      for (int o = 1; o < G; o <<= 1)       // ascending: the order bn_relu_apply_head's DPP sum reproduces bit for bit
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
           for (int i = 0; i < E; ++i) acc[k] = fmaf(v[i], wl[k * Cin + p * E + i], acc[k]);
       }
     }
-    for (int o = G >> 1; o > 0; o >>= 1)
+    for (int o = 1; o < G; o <<= 1)       // ascending: the order bn_relu_apply_head's DPP sum reproduces bit for bit
 #pragma unroll
       for (int k = 0; k < CT; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
     if (sub == 0 && pix < npix) {

@@ -647,7 +647,8 @@ def test_bn_relu_bwd_with_head_gradient_equals_conv1x1_dgrad_then_bn_bwd(dtype, 
 
 
 @pytest.mark.parametrize('dtype', BOTH)
-@pytest.mark.parametrize('ncls,npix_shape', [(1, (2, 9, 13)), (2, (1, 16, 16)), (2, (2, 7, 11)), (3, (1, 5, 9)), (4, (2, 6, 7))])
+@pytest.mark.parametrize('ncls,npix_shape', [(1, (2, 9, 13)), (2, (1, 16, 16)), (2, (2, 7, 11)), (3, (1, 5, 9)), (4, (2, 6, 7)),
+                                             (2, (2, 96, 131))])     # many pixels: the DPP pixel sum of the 16-bit form
 def test_bn_relu_apply_head_equals_apply_then_conv1x1(dtype, ncls, npix_shape):
     """Last block forward (unet_parts.py:20-21 then :74): the fused kernel's activation must equal bn_relu_apply's bit
     for bit, its logits conv1x1_fwd's on that activation (same per-lane fma chain and shuffle order: bit for bit)."""
