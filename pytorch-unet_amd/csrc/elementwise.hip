@@ -191,27 +191,29 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
     const int y0 = 2 * qy, x0 = 2 * qx;
     const bool has_x1 = x0 + 1 < W, has_y1 = y0 + 1 < H;
     const long p00 = (n * H + y0) * W + x0;
+    // clamped addresses instead of branches: an absent pixel re-reads a present one and is never stored, and all four
+    // loads are in flight together
+    const long p01 = p00 + (has_x1 ? 1 : 0), p10 = p00 + (has_y1 ? W : 0), p11 = p10 + (has_x1 ? 1 : 0);
     float v[4][E];
     Vec<T>::load(y + p00 * ldy + c0, v[0]);
-    if (has_x1) Vec<T>::load(y + (p00 + 1) * ldy + c0, v[1]);
-    if (has_y1) Vec<T>::load(y + (p00 + W) * ldy + c0, v[2]);
-    if (has_x1 && has_y1) Vec<T>::load(y + (p00 + W + 1) * ldy + c0, v[3]);
+    Vec<T>::load(y + p01 * ldy + c0, v[1]);
+    Vec<T>::load(y + p10 * ldy + c0, v[2]);
+    Vec<T>::load(y + p11 * ldy + c0, v[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int i = 0; i < E; ++i) v[k][i] = fmaxf(fmaf(v[k][i], sc[i], sh[i]), 0.f);
     Vec<T>::store(out + p00 * ldo + c0, v[0]);
-    if (has_x1) Vec<T>::store(out + (p00 + 1) * ldo + c0, v[1]);
-    if (has_y1) Vec<T>::store(out + (p00 + W) * ldo + c0, v[2]);
+    if (has_x1) Vec<T>::store(out + p01 * ldo + c0, v[1]);
+    if (has_y1) Vec<T>::store(out + p10 * ldo + c0, v[2]);
     if (has_x1 && has_y1) {
-      Vec<T>::store(out + (p00 + W + 1) * ldo + c0, v[3]);
+      Vec<T>::store(out + p11 * ldo + c0, v[3]);
       float m[E];
 #pragma unroll
       for (int i = 0; i < E; ++i) {
-        // the pooled value is the maximum of the STORED activations (rounded to T), as MaxPool2d sees them
-        const float a = to_f32(from_f32<T>(v[0][i])), b = to_f32(from_f32<T>(v[1][i]));
-        const float c = to_f32(from_f32<T>(v[2][i])), d = to_f32(from_f32<T>(v[3][i]));
-        m[i] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+        // the pooled value is the maximum of the STORED activations (rounded to T), as MaxPool2d sees them: rounding is
+        // monotone, so that is the rounded maximum of the unrounded ones -- the store below rounds it
+        m[i] = fmaxf(fmaxf(v[0][i], v[1][i]), fmaxf(v[2][i], v[3][i]));
       }
       Vec<T>::store(pool + ((n * PH + qy) * PW + qx) * ldp + c0, m);
     }
