@@ -285,6 +285,36 @@ def test_bn_relu_train_fwd_bwd(dtype, c):
 
 
 @pytest.mark.parametrize('dtype', BOTH)
+@pytest.mark.parametrize('pooled', [False, True])
+def test_bn_relu_bwd_sums_with_offset_channels(dtype, pooled):
+    """The reductions accumulate their second sum as sum dz*y in 16-bit tensors and subtract mean * sum dz once per
+    thread (elementwise.hip: s2_step / s2_final).  Channels whose mean is many standard deviations from zero are where
+    that cancels: dgamma / dbeta must still match the fp64 oracle on the same stored values."""
+    from oracle import ops_numpy as O
+    from unetk import ops
+    n, h, w, c = 2, 40, 50, 64
+    y = _rand((n, h, w, c), 145, 0.25, 6.0).to(dtype)             # mean 6, half-width 0.25: |mean| / std about 40
+    y[..., ::2] -= 12.0                                           # every other channel sits at -6
+    dout = _rand((n, h, w, c), 146, 0.1).to(dtype)
+    bn = _BN(c)
+    y64 = _np(y)
+    stats = ops.new_stats(c, 'cuda')
+    stats[0, :, 0] = torch.from_numpy(y64.reshape(-1, c).sum(0)).cuda()
+    stats[0, :, 1] = torch.from_numpy((y64 * y64).reshape(-1, c).sum(0)).cuda()
+    st = ops.BNState(c, 'cuda')
+    ops.bn_train_finalize(stats, n * h * w, bn, st, 0.1, 1e-5)
+    z, mean, var, invstd = O.bn_train_fwd(y64, _np(bn.weight), _np(bn.bias))
+    dgamma, dbeta = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    if pooled:
+        dpool = torch.zeros((n, h // 2, w // 2, c), dtype=dtype, device='cuda')     # no pooled gradient: same sums
+        ops.bn_relu_bwd(dout.cuda(), y.cuda(), st, bn.weight, dgamma, dbeta, dpool=dpool)
+    else:
+        ops.bn_relu_bwd(dout.cuda(), y.cuda(), st, bn.weight, dgamma, dbeta)
+    _, rdg, rdb = O.bn_relu_train_bwd(y64, _np(bn.weight), mean, invstd, O.relu(z), _np(dout))
+    assert rel_err(_np(dgamma), rdg) < 1e-3 and rel_err(_np(dbeta), rdb) < 1e-3
+
+
+@pytest.mark.parametrize('dtype', BOTH)
 def test_bn_eval(dtype):
     from oracle import ops_numpy as O
     from unetk import ops
