@@ -413,6 +413,31 @@ __device__ __forceinline__ void act_pair(float p0, float p1, float& a0, float& a
   }
 }
 
+// Walks the 2x2 quads of an [N][QH][QW] grid with a fixed stride: (n, qy, qx) advance by the stride's own decomposition
+// (wave-uniform) with two carries per step instead of two 64-bit divisions per quad -- the pool kernels are bound by
+// their instruction count (the forward bn_relu_apply_pool_kernel is not: there the walker measured 4 % slower).
+// 32-bit counters: the host entry points refuse grids of 2^31 quads or more.
+struct QuadWalk {
+  int qx, qy, n, q;
+  int sx, sy, sn, stride, QW, QH, nquads;
+  __device__ __forceinline__ QuadWalk(int first, int stride_, int nquads_, int QH_, int QW_)
+      : q(first), stride(stride_), QW(QW_), QH(QH_), nquads(nquads_) {
+    qx = first % QW; int r = first / QW; qy = r % QH; n = r / QH;
+    sx = stride % QW; r = stride / QW; sy = r % QH; sn = r / QH;
+  }
+  __device__ __forceinline__ bool valid() const { return q < nquads; }
+  __device__ __forceinline__ void next() {
+    q += stride;
+    qx += sx;
+    const bool cx = qx >= QW;
+    qx -= cx ? QW : 0;
+    qy += sy + (cx ? 1 : 0);
+    const bool cy = qy >= QH;
+    qy -= cy ? QH : 0;
+    n += sn + (cy ? 1 : 0);
+  }
+};
+
 template <typename T>
 struct QuadGrad {
   static constexpr int E = Vec<T>::E;
@@ -425,13 +450,16 @@ struct QuadGrad {
     hx = x0 + 1 < W;
     hy = y0 + 1 < H;
     const long p00 = (n * H + y0) * W + x0;
-    // clamped addresses instead of branches: an absent pixel re-reads pixel 0 of the quad and is masked on use
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long p = p00 + (((k >> 1) && hy) ? W : 0) + (((k & 1) && hx) ? 1 : 0);
-      v[k] = raw_load(y + p * ldy + c0);
-      g[k] = raw_load(dskip + p * ldds + c0);
-    }
+    // clamped addresses instead of branches: an absent pixel re-reads pixel 0 of the quad and is masked on use.
+    // One 64-bit product per tensor; the other three pixels are that address plus the (selected) pixel / row pitch.
+    const T* yq = y + p00 * ldy + c0;
+    const T* gq = dskip + p00 * ldds + c0;
+    const long yx = hx ? ldy : 0, yr = hy ? (long)W * ldy : 0;
+    const long gx = hx ? ldds : 0, gr = hy ? (long)W * ldds : 0;
+    v[0] = raw_load(yq);           g[0] = raw_load(gq);
+    v[1] = raw_load(yq + yx);      g[1] = raw_load(gq + gx);
+    v[2] = raw_load(yq + yr);      g[2] = raw_load(gq + gr);
+    v[3] = raw_load(yq + yr + yx); g[3] = raw_load(gq + gr + gx);
     const int py = hy ? qy : max(qy - 1, 0), px = hx ? qx : max(qx - 1, 0);      // any valid pooled pixel
     gp = raw_load(dpool + ((n * (H / 2) + py) * (W / 2) + px) * lddp + c0);
   }
@@ -476,12 +504,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_pool_kernel(
   }
   const int QH = (H + 1) / 2, QW = (W + 1) / 2;
   const long nquads = (long)N * QH * QW;
-  for (long q = (long)blockIdx.x * lanes + plane; q < nquads; q += (long)gridDim.x * lanes) {
-    const int qx = (int)(q % QW);
-    const long r = q / QW;
-    const int qy = (int)(r % QH);
+  for (QuadWalk it(blockIdx.x * lanes + plane, gridDim.x * lanes, (int)nquads, QH, QW); it.valid(); it.next()) {
     QuadGrad<T> Q;
-    Q.load(dskip, ldds, dpool, lddp, y, ldy, r / QH, qy, qx, H, W, c0);
+    Q.load(dskip, ldds, dpool, lddp, y, ldy, it.n, it.qy, it.qx, H, W, c0);
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       float yv[4], gv[4];
@@ -523,11 +548,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_pool_kernel(
   }
   const int QH = (H + 1) / 2, QW = (W + 1) / 2;
   const long nquads = (long)N * QH * QW;
-  for (long q = (long)blockIdx.x * lanes + plane; q < nquads; q += (long)gridDim.x * lanes) {
-    const int qx = (int)(q % QW);
-    const long r = q / QW;
-    const int qy = (int)(r % QH);
-    const long n = r / QH;
+  for (QuadWalk it(blockIdx.x * lanes + plane, gridDim.x * lanes, (int)nquads, QH, QW); it.valid(); it.next()) {
+    const int qx = it.qx, qy = it.qy;
+    const long n = it.n;
     QuadGrad<T> Q;
     Q.load(dskip, ldds, dpool, lddp, y, ldy, n, qy, qx, H, W, c0);
     float o[4][E];
@@ -1395,6 +1418,7 @@ int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool
   if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
   const int E = unetk_epp(dtype);
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  if (nquads >= (1L << 30)) return UNETK_ERR_SHAPE;          // 32-bit quad counters (QuadWalk)
   const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dskip, ldds, (const T*)dpool, lddp, (const T*)y, ldy, scale, shift, mean,
@@ -1410,6 +1434,7 @@ int unetk_bn_relu_bwd_apply_pool(const void* dskip, int ldds, const void* dpool,
   if (!scale || !shift || !mean || !coef || !dy || lddy < c) return UNETK_ERR_ARG;
   const int E = unetk_epp(dtype);
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
+  if (nquads >= (1L << 30)) return UNETK_ERR_SHAPE;          // 32-bit quad counters (QuadWalk)
   const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dskip, ldds, (const T*)dpool, lddp, (const T*)y, ldy, scale, shift, mean,
