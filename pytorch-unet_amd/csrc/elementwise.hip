@@ -596,11 +596,9 @@ struct HeadQuad {
                                        long npix, int c0) {
     const long p0 = 4 * q;
     const bool full = p0 + 3 < npix;
+    const T* yq = y + p0 * ldy + c0;                              // one 64-bit product; the pixels are pitches apart
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long p = p0 + u < npix ? p0 + u : p0;               // clamped; masked by the callers
-      yraw[u] = raw_load(y + p * ldy + c0);
-    }
+    for (int u = 0; u < 4; ++u) yraw[u] = raw_load(yq + (p0 + u < npix ? u * ldy : 0));   // clamped; masked by the callers
     if (kVector && full && lddl == NCLS && (reinterpret_cast<uintptr_t>(dl) & 15) == 0) {
       uint4 v[NV];
 #pragma unroll
@@ -848,6 +846,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_head_kernel(
   for (long q = (long)blockIdx.x * lanes + plane; q < ngroups; q += (long)gridDim.x * lanes) {
     HeadQuad<T, NCLS> Q;
     Q.load(dl, lddl, y, ldy, q, npix, c0);
+    T* dyq = dy + 4 * q * lddy + c0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (4 * q + u >= npix) break;
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_head_kernel(
         const float dz = fmaf(v, sc[i], sh[i]) > 0.f ? g : 0.f;
         o[i] = ka[i] * dz - kb[i] - kc[i] * (v - mu[i]);
       }
-      Vec<T>::store(dy + (4 * q + u) * lddy + c0, o);
+      Vec<T>::store(dyq + u * lddy, o);
     }
   }
 }
@@ -1311,7 +1310,10 @@ int unetk_bn_relu_apply_head(const void* y, int ldy, const float* scale, const f
   const int ppp = c / E;
   // a pixel's lanes must share a wave for the shuffle sum: ppp a power of two <= 64
   if (n_classes < 1 || n_classes > kHeadMax || ldl < n_classes || ppp > 64 || (ppp & (ppp - 1))) return UNETK_ERR_SHAPE;
-  const int grid = ew_grid((npix + 3) / 4, 256 / ppp, 256 * EW_APPLY_MUL);
+  // 80 registers: six blocks fit a CU, and the pass is latency-bound below that (512 blocks 0.323 ms, 1024 0.261,
+  // 1536 0.254, 4096 0.248 at 16 x 640 x 959 x 64: scripts/perf_head.py)
+  UNETK_KNOB(hcap, "UNETK_HEAD_GRID", 4096);
+  const int grid = ew_grid((npix + 3) / 4, 256 / ppp, hcap);
   // STORE: the activation itself is wanted too (out != NULL); the training forward of the whole net passes NULL
 #define HEAD_FWD_S(NC, ST)                                                                                          \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_apply_head_kernel<T, NC, ST>), dim3(grid), dim3(256), 0,             \
@@ -1349,7 +1351,8 @@ int unetk_bn_relu_bwd_reduce_head(const void* dl, int lddl, const float* w, int 
   if (int e = head_bwd_check(dl, lddl, w, n_classes, y, ldy, npix, c, dtype)) return e;
   if (!scale || !shift || !mean || !invstd || !sums) return UNETK_ERR_ARG;
   const int E = unetk_epp(dtype);
-  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 1024);
+  UNETK_KNOB(rcap, "UNETK_HEADR_GRID", 1024);
+  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), rcap);
 #define HEAD_REDUCE(NC)                                                                                              \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_head_kernel<T, NC>), dim3(grid), dim3(256), 0,            \
                                        (hipStream_t)stream, (const T*)dl, lddl, w, (const T*)y, ldy, scale, shift,   \
@@ -1381,7 +1384,8 @@ int unetk_bn_relu_bwd_apply_head(const void* dl, int lddl, const float* w, int n
   if (!scale || !shift || !mean || !coef) return UNETK_ERR_ARG;
   if (int e = check_act(dy, lddy, c, dtype)) return e;
   const int E = unetk_epp(dtype);
-  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), 256 * EW_BWD_MUL);
+  UNETK_KNOB(acap, "UNETK_HEADA_GRID", 1536);         // whole rounds of three blocks per CU (1024: 0.468 ms, 1536: 0.450)
+  const int grid = ew_grid((npix + 3) / 4, 256 / (c / E), acap);
 #define HEAD_APPLY(NC)                                                                                               \
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_apply_head_kernel<T, NC>), dim3(grid), dim3(256), 0,             \
                                        (hipStream_t)stream, (const T*)dl, lddl, w, (const T*)y, ldy, scale, shift,   \
@@ -1419,7 +1423,10 @@ int unetk_bn_relu_bwd_reduce_pool(const void* dskip, int ldds, const void* dpool
   const int E = unetk_epp(dtype);
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
   if (nquads >= (1L << 30)) return UNETK_ERR_SHAPE;          // 32-bit quad counters (QuadWalk)
-  const int grid = ew_grid(nquads, 256 / (c / E), 256 * EW_BWD_MUL);
+  // two blocks per CU (172 registers): one whole round; fewer blocks also means fewer fp64 atomics at the deep levels
+  // (1024 blocks: 0.508 / 0.218 / 0.119 / 0.072 ms at the four encoder levels, 512: 0.498 / 0.213 / 0.112 / 0.060)
+  UNETK_KNOB(pcap, "UNETK_POOLR_GRID", 512);
+  const int grid = ew_grid(nquads, 256 / (c / E), pcap);
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_bwd_reduce_pool_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dskip, ldds, (const T*)dpool, lddp, (const T*)y, ldy, scale, shift, mean,
                                        invstd, sums, n, h, w, c));

@@ -35,7 +35,10 @@ calls = {
                                                                           coef.data_ptr(), dy.data_ptr(), C, npix, C, dc, st),
                                npix * (2 * C + K) * es),
 }
+only = os.environ.get('ONLY')
 for name, (f, nbytes) in calls.items():
+    if only and only not in name:
+        continue
     check(f(), name)
     torch.cuda.synchronize()
     reps = 20
