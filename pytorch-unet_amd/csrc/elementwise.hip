@@ -1611,7 +1611,8 @@ int unetk_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const f
   const int ppp = c / unetk_epp(dtype);
   if (ppp > 256 || 256 % ppp) return UNETK_ERR_SHAPE;   // callers fall back to apply + maxpool2x2_fwd
   const long nquads = (long)n * ((h + 1) / 2) * ((w + 1) / 2);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_pool_kernel<T>, dim3(ew_grid(nquads, 256 / ppp, 256 * 4)), dim3(256),
+  UNETK_KNOB(fcap, "UNETK_POOLF_GRID", 256 * 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_apply_pool_kernel<T>, dim3(ew_grid(nquads, 256 / ppp, fcap)), dim3(256),
                                        0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, (T*)out, ldo, (T*)pool,
                                        ldp, n, h, w, c));
   UNETK_CHECK_LAUNCH();
